@@ -1,0 +1,163 @@
+/*
+ * rdst_hip.h — C ABI of the MI355X (gfx950) radix-sort hot path that sits behind
+ * rdst's RadixSort / RadixKey / Tuner surface.
+ *
+ * The reference crate (nessex/rdst) has no FFI of its own; every entry point below
+ * names the reference interface it stands in for (paths relative to the reference
+ * tree, file:line).  A Rust shim binds these with a plain `extern "C"` block
+ * (INTEGRATION.md shows it); this repo's own host mirrors (include/rdst.hpp for
+ * C++, rdst_amd/ for Python) call exactly the same symbols.
+ *
+ * Conventions
+ *   - every function returns 0 (RDST_OK) or a negative rdst_status; on any non-zero
+ *     return the caller's key buffer is unmodified for the host entry point
+ *     (rdst_hip_sort), so a shim can fall back to the CPU path and still honour
+ *     rdst's infallible `fn sort(self)` contract (src/radix_sort_builder.rs:149-157).
+ *   - plain pointers and sizes only; `stream` is a hipStream_t passed as void*
+ *     (NULL = the default stream).
+ *   - device pointers must be aligned to the element size; 16-byte alignment gets
+ *     the wide-load kernels.
+ *   - the library owns its device workspace (histograms, look-back status words,
+ *     tickets): one per device, grown on demand, process lifetime, mutex-guarded.
+ *     Concurrent calls on one device serialise on that mutex.
+ */
+#ifndef RDST_HIP_H
+#define RDST_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RDST_HIP_ABI_VERSION 1
+
+/* Which built-in RadixKey mapping the element type uses (src/radix_key_impl.rs). */
+typedef enum {
+    RDST_KEY_UNSIGNED = 0, /* u8..u64: (self >> level*8) as u8          radix_key_impl.rs:3-76   */
+    RDST_KEY_SIGNED   = 1, /* i8..i64: ((self ^ MIN) >> level*8) as u8  radix_key_impl.rs:87-160 */
+    RDST_KEY_FLOAT    = 2  /* f32/f64: sign-magnitude flip, then ^ MIN  radix_key_impl.rs:162-185 */
+} rdst_key_kind;
+
+typedef enum {
+    RDST_OK              = 0,
+    RDST_ERR_ARG         = -1, /* bad pointer / size / kind / levels (LEVELS == 0 panics in rdst: radix_sort_builder.rs:22) */
+    RDST_ERR_UNSUPPORTED = -2, /* element width not built for the device path */
+    RDST_ERR_HIP         = -3, /* a HIP runtime call failed; see rdst_hip_last_error() */
+    RDST_ERR_NO_DEVICE   = -4, /* no usable gfx950 device */
+    RDST_ERR_DEVICE      = -5, /* a kernel reported failure through the workspace error word (bounded spin expired) */
+    RDST_ERR_ALIGN       = -6  /* pointer not aligned to the element size */
+} rdst_status;
+
+/* src/tuner.rs:2-8.  parent_len: -1 encodes None. */
+typedef struct {
+    uint64_t threads;
+    uint64_t level;
+    uint64_t total_levels;
+    uint64_t input_len;
+    int64_t  parent_len;
+} rdst_tuning_params;
+
+/* src/tuner.rs:12-22, in declaration order, plus the two device routes a GPU-aware
+ * tuner may return (they need a new arm in the `match` at src/sorter.rs:81-102). */
+typedef enum {
+    RDST_ALGO_MT_OOP = 0,
+    RDST_ALGO_MT_LSB = 1,
+    RDST_ALGO_SCANNING = 2,
+    RDST_ALGO_RECOMBINATING = 3,
+    RDST_ALGO_COMPARATIVE = 4,
+    RDST_ALGO_LR_LSB = 5,
+    RDST_ALGO_LSB = 6,
+    RDST_ALGO_REGIONS = 7,
+    RDST_ALGO_SKA = 8,
+    RDST_ALGO_GPU_LSD = 9,      /* whole slice on one device: rdst_hip_sort / rdst_hip_sort_device */
+    RDST_ALGO_GPU_SHARDED = 10  /* slice spread over ranks: MSD split + exchange + local LSD */
+} rdst_algorithm;
+
+/* Stock tuners (src/tuners/, one file each) + the device-aware one. */
+typedef enum {
+    RDST_TUNER_STANDARD = 0,        /* src/tuners/standard_tuner.rs:10-64 */
+    RDST_TUNER_LOW_MEMORY = 1,      /* src/tuners/low_memory_tuner.rs:13-43 */
+    RDST_TUNER_SINGLE_THREADED = 2, /* src/tuners/single_threaded_tuner.rs:13-43 */
+    RDST_TUNER_GPU = 3              /* StandardTuner, except depth-0 chunks >= gpu_min_len go to GPU_LSD */
+} rdst_tuner_id;
+
+/* Options of the host entry point.  NULL = defaults. */
+typedef struct {
+    int32_t  device;       /* HIP device ordinal, -1 = current device */
+    int32_t  reserved0;
+    uint64_t reserved1;
+} rdst_hip_opts;
+
+/* ---- entry points ------------------------------------------------------------------ */
+
+/* Replaces `RadixSort::radix_sort_unstable` for a host slice of a built-in key type
+ * (src/radix_sort.rs:21-45 -> src/radix_sort_builder.rs:149-157 -> src/sorter.rs:106-119).
+ * Sorts `len` elements of `elem_bytes` bytes in place, ascending in rdst's mapped-key
+ * order.  Blocking.  len <= 1 is a no-op (radix_sort_builder.rs:151).  `levels` must
+ * equal elem_bytes (RadixKey::LEVELS of every built-in type).  On failure the buffer
+ * is untouched. */
+int rdst_hip_sort(void* host_data, uint64_t len, uint32_t elem_bytes, rdst_key_kind kind,
+                  uint32_t levels, const rdst_hip_opts* opts);
+
+/* Device-resident form of the same call — the timed path.  `dev_keys` holds the keys and
+ * receives the sorted result; `dev_tmp` is a caller-provided scratch of the same size
+ * (the `tmp_bucket` of src/sorts/lsb_sort.rs:53).  Asynchronous on `stream`.  The LSD
+ * pass loop is the device twin of Sorter::lsb_sort_adapter (src/sorts/lsb_sort.rs:39-127)
+ * with mt_lsb_sort's (bucket, tile) offset table (src/sorts/mt_lsb_sort.rs:40-133)
+ * replaced by an on-device chained scan. */
+int rdst_hip_sort_device(void* dev_keys, void* dev_tmp, uint64_t len, uint32_t elem_bytes,
+                         rdst_key_kind kind, uint32_t levels, void* stream);
+
+/* Blocks until everything queued on `stream` by this library has finished and returns
+ * RDST_ERR_DEVICE if any kernel raised the workspace error word since the last check. */
+int rdst_hip_device_status(void* stream);
+
+/* Parity hook for get_counts_with_ends (src/sort_utils.rs:109-180) /
+ * par_get_counts_with_ends (:35-106): 256-bin histogram of digit `level` over a
+ * device-resident slice, plus the `already_sorted` flag (digit sequence non-decreasing)
+ * and the first and last digit.  Blocking.  Empty input: counts all zero, sorted = 1,
+ * first = last = 0 (sort_utils.rs:116-118). */
+int rdst_hip_level_counts(const void* dev_keys, uint64_t len, uint32_t elem_bytes,
+                          rdst_key_kind kind, uint32_t level, uint64_t counts[256],
+                          uint8_t* already_sorted, uint8_t* first_digit, uint8_t* last_digit,
+                          void* stream);
+
+/* Parity hook for the fused multi-level histogram kernel: counts_out[level*256 + digit]
+ * for every level in [0, levels).  Same numbers get_counts (sort_utils.rs:183-190)
+ * returns level by level.  Blocking. */
+int rdst_hip_all_level_counts(const void* dev_keys, uint64_t len, uint32_t elem_bytes,
+                              rdst_key_kind kind, uint32_t levels, uint64_t* counts_out,
+                              void* stream);
+
+/* Parity hook for one stable counting-sort pass: out_of_place_sort
+ * (src/sorts/out_of_place_sort.rs:52-108) / mt_lsb_sort (src/sorts/mt_lsb_sort.rs:40-133)
+ * on digit `level`: dev_dst[prefix[d]++] = dev_src[i] in index order.  This is also the
+ * MSD split of the sharded route (top level, then contiguous digit ranges per rank).
+ * counts_out (nullable) receives the 256 digit counts.  Blocking. */
+int rdst_hip_scatter_level(const void* dev_src, void* dev_dst, uint64_t len, uint32_t elem_bytes,
+                           rdst_key_kind kind, uint32_t level, uint64_t* counts_out, void* stream);
+
+/* Replaces `Tuner::pick_algorithm` (src/tuner.rs:33-35) for the stock tuners: pure
+ * integer decision tables, host only.  counts has 256 entries (src/sorter.rs:67-76).
+ * gpu_min_len is read only by RDST_TUNER_GPU. */
+int rdst_pick_algorithm(int tuner_id, const rdst_tuning_params* p, const uint64_t counts[256],
+                        uint64_t gpu_min_len);
+
+/* Bytes of device memory the workspace needs for a sort of `len` elements. */
+uint64_t rdst_hip_workspace_bytes(uint64_t len, uint32_t elem_bytes);
+
+/* Runtime knobs for experiments (kernel shape, number of look-back chains).  Values
+ * <= 0 restore the built-in choice.  Not part of the reference surface. */
+int rdst_hip_set_tuning(int chains, int pass_config, int hist_blocks_per_cu);
+
+/* Last error message of the calling thread ("" if none). */
+const char* rdst_hip_last_error(void);
+
+/* ABI version of the loaded library (RDST_HIP_ABI_VERSION at build time). */
+int rdst_hip_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RDST_HIP_H */

@@ -1,0 +1,40 @@
+"""In-tree build of the HIP extension (gfx950 only) — explicit hipcc, no JIT cache, so the
+built ``librdst_hip.so`` travels with the repo snapshot to the GPU box."""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SOURCES = [os.path.join(HERE, "csrc", "rdst_kernels.hip"), os.path.join(HERE, "csrc", "rdst_tuner.cpp")]
+HEADERS = [os.path.join(ROOT, "include", "rdst_hip.h")]
+OUT = os.path.join(HERE, "librdst_hip.so")
+
+
+def _hipcc():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found; the device route cannot be built (there is no CPU fallback)")
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    return any(os.path.getmtime(p) > t for p in SOURCES + HEADERS)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return OUT
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-Wno-unused-result", "-I", os.path.join(ROOT, "include"), *SOURCES, "-o", OUT]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

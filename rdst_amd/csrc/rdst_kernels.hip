@@ -1,0 +1,912 @@
+// rdst_kernels.hip — gfx950 (MI355X, CDNA4) radix-sort hot path + its C ABI (include/rdst_hip.h).
+//
+// What is here, and which reference function each piece is the device twin of
+// (paths relative to the reference tree):
+//
+//   K1 hist_kernel        one coalesced read of the key slice -> 256-bin histograms of EVERY
+//                         level, per look-back chain.            get_counts_with_ends
+//                         (src/sort_utils.rs:109-180), get_tile_counts (:193-244)
+//   K2 scan_kernel        256-bin exclusive scan per level + the (chain, digit) offset table
+//                         + the level-skip plan.                 get_prefix_sums (:10-20),
+//                         the (bucket, tile) carve of mt_lsb_sort (src/sorts/mt_lsb_sort.rs:51-54),
+//                         level skipping of lsb_sort_adapter (src/sorts/lsb_sort.rs:62-83)
+//   K3 onesweep_kernel    one stable counting-sort pass: wave-ballot ranking, tile prefix by
+//                         chained scan with decoupled look-back. out_of_place_sort
+//                         (src/sorts/out_of_place_sort.rs:52-108), mt_lsb_sort (:40-133)
+//   K4 key map            fused into K1/K3 digit extraction.     src/radix_key_impl.rs:3-185
+//   K6 level_counts_kernel single-level histogram + already_sorted flag (parity hook)
+//
+// Data layout in HBM: keys are a dense array of K (u32 / u64 bit patterns; signed and float
+// keys stay in their raw encoding in memory, the order-preserving map is applied in registers
+// for digit extraction only).  `keys` and `tmp` ping-pong per executed pass.  The workspace
+// holds, per sort: an error word, per-(level, chain) tile tickets, the plan, per-chain
+// histograms u32[C][L][256], look-back status words u32[L][tiles][256], and the offset table
+// u64[L][C][256].
+//
+// Written for wave64 / 256 CUs in 8 XCDs only; no other target is supported.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "rdst_hip.h"
+
+namespace {
+
+constexpr int RADIX = 256;
+constexpr int MAX_LEVELS = 16;
+constexpr int MAX_CHAINS = 64;
+
+// look-back status word: [31:30] state, [29:0] value
+constexpr uint32_t ST_EMPTY = 0, ST_AGG = 1, ST_INCL = 2;
+constexpr uint32_t ST_VALUE_MASK = (1u << 30) - 1;
+// bounded spins: s_sleep(2) is ~128 clocks; 1<<22 polls is seconds, never reached in a healthy run
+constexpr uint32_t SPIN_LIMIT = 1u << 22;
+
+constexpr uint32_t ERR_LOOKBACK_TIMEOUT = 1;
+
+struct Plan {
+    uint32_t skip[MAX_LEVELS];        // pass would move nothing (one bin holds every key)
+    uint32_t src_is_tmp[MAX_LEVELS];  // which buffer the pass reads
+    uint32_t result_in_tmp;           // where the data sits after the last executed pass
+    uint32_t executed;                // number of passes executed
+};
+
+struct KeyMap {  // order-preserving map as two xor masks (src/radix_key_impl.rs)
+    uint64_t neg;  // xor applied when the sign bit is set
+    uint64_t pos;  // xor applied when it is clear
+};
+
+template <typename K>
+__device__ __forceinline__ K map_key(K k, K neg, K pos) {
+    constexpr int W = sizeof(K) * 8;
+    return k ^ ((k >> (W - 1)) ? neg : pos);
+}
+template <typename K>
+__device__ __forceinline__ K unmap_key(K m, K neg, K pos) {
+    constexpr int W = sizeof(K) * 8;
+    return m ^ ((m >> (W - 1)) ? pos : neg);
+}
+template <typename K>
+__device__ __forceinline__ uint32_t digit_of(K mapped, int shift) {
+    return (uint32_t)(mapped >> shift) & 0xFFu;
+}
+
+__device__ __forceinline__ uint32_t ld_relaxed(const uint32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_relaxed(uint32_t* p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// lanes of this wave holding the same 8-bit digit (all 64 lanes must be active)
+__device__ __forceinline__ uint64_t match_any8(uint32_t d) {
+    uint64_t m = ~0ull;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const bool bit = (d >> b) & 1u;
+        const uint64_t bal = __ballot(bit);
+        m &= bit ? bal : ~bal;
+    }
+    return m;
+}
+__device__ __forceinline__ uint32_t lanes_below(uint64_t mask) {  // popcount(mask & lanes < me)
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// ------------------------------------------------------------------------------------------
+// K1: every level's histogram from one read.  grid = C * blocks_per_chain, block = 256.
+// Per-wave 256-bin histograms in LDS (one copy per wave and level), block reduce, one global
+// atomic per non-empty (level, digit).  VEC = keys per 16-byte load (1 = unaligned fallback).
+// ------------------------------------------------------------------------------------------
+template <typename K, int LEVELS, int VEC>
+__global__ __launch_bounds__(256) void hist_kernel(const K* __restrict__ keys, uint64_t n,
+                                                   uint64_t chain_len, uint32_t blocks_per_chain,
+                                                   K neg, K pos, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t s_h[4][LEVELS][RADIX];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    for (int i = tid; i < 4 * LEVELS * RADIX; i += 256) (&s_h[0][0][0])[i] = 0;
+    __syncthreads();
+
+    const uint32_t chain = blockIdx.x / blocks_per_chain;
+    const uint32_t bic = blockIdx.x % blocks_per_chain;
+    const uint64_t c_begin = (uint64_t)chain * chain_len;
+    const uint64_t c_end = (c_begin + chain_len < n) ? c_begin + chain_len : n;
+    if (c_begin < c_end) {
+        const uint64_t c_cnt = c_end - c_begin;
+        constexpr uint64_t GRAN = 256ull * VEC * 4;  // one unrolled sweep of the block
+        uint64_t piece = (c_cnt + blocks_per_chain - 1) / blocks_per_chain;
+        piece = (piece + GRAN - 1) / GRAN * GRAN;
+        const uint64_t p_begin = c_begin + (uint64_t)bic * piece;
+        uint64_t p_end = p_begin + piece;
+        if (p_end > c_end) p_end = c_end;
+        uint32_t(*wh)[RADIX] = s_h[wave];
+
+        struct alignas(sizeof(K) * VEC) V { K e[VEC]; };
+        uint64_t i = p_begin + (uint64_t)tid * VEC;
+        constexpr uint64_t STRIDE = 256ull * VEC;
+        // full sweeps: 4 independent 16-byte loads in flight per lane
+        for (; p_begin < p_end && i + 3 * STRIDE + VEC <= p_end; i += 4 * STRIDE) {
+            V v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const V*>(keys + i + u * STRIDE);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const K m = map_key<K>(v[u].e[e], neg, pos);
+#pragma unroll
+                    for (int l = 0; l < LEVELS; ++l) atomicAdd(&wh[l][digit_of(m, l * 8)], 1u);
+                }
+        }
+        // remainder of the piece, element-wise
+        for (; i < p_end; i += STRIDE) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                if (i + e < p_end) {
+                    const K m = map_key<K>(keys[i + e], neg, pos);
+#pragma unroll
+                    for (int l = 0; l < LEVELS; ++l) atomicAdd(&wh[l][digit_of(m, l * 8)], 1u);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t* out = hist + (size_t)chain * LEVELS * RADIX;
+    for (int i = tid; i < LEVELS * RADIX; i += 256) {
+        const int l = i >> 8, d = i & 255;
+        const uint32_t s = s_h[0][l][d] + s_h[1][l][d] + s_h[2][l][d] + s_h[3][l][d];
+        if (s) atomicAdd(&out[i], s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2: one block of 256 threads.  For every level: total per digit over chains, exclusive scan
+// over digits (u64), offset table base[level][chain][digit], and the skip plan.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void scan_kernel(const uint32_t* __restrict__ hist,
+                                                   uint64_t* __restrict__ base, Plan* plan,
+                                                   uint64_t* __restrict__ totals_out,
+                                                   uint32_t C, uint32_t levels, uint64_t n,
+                                                   uint32_t allow_skip, uint32_t level_lo,
+                                                   uint32_t level_hi) {
+    __shared__ uint64_t s_scan[RADIX];
+    __shared__ uint32_t s_trivial[MAX_LEVELS];
+    const int d = threadIdx.x;
+    if (d < MAX_LEVELS) s_trivial[d] = 0;
+    __syncthreads();
+    for (uint32_t l = 0; l < levels; ++l) {
+        uint64_t total = 0;
+        for (uint32_t c = 0; c < C; ++c) total += hist[((size_t)c * levels + l) * RADIX + d];
+        if (totals_out) totals_out[(size_t)l * RADIX + d] = total;
+        if (total == n) s_trivial[l] = 1;
+        // Hillis-Steele inclusive scan over 256 u64 values
+        s_scan[d] = total;
+        __syncthreads();
+        for (int o = 1; o < RADIX; o <<= 1) {
+            const uint64_t y = (d >= o) ? s_scan[d - o] : 0;
+            __syncthreads();
+            s_scan[d] += y;
+            __syncthreads();
+        }
+        uint64_t run = s_scan[d] - total;
+        for (uint32_t c = 0; c < C; ++c) {
+            base[((size_t)l * C + c) * RADIX + d] = run;
+            run += hist[((size_t)c * levels + l) * RADIX + d];
+        }
+        __syncthreads();
+    }
+    if (d == 0) {
+        uint32_t in_tmp = 0, executed = 0;
+        for (uint32_t l = 0; l < MAX_LEVELS; ++l) {
+            const bool active = l >= level_lo && l < level_hi && l < levels;
+            const bool skip = !active || (allow_skip && s_trivial[l]);
+            plan->skip[l] = skip ? 1u : 0u;
+            plan->src_is_tmp[l] = in_tmp;
+            if (!skip) { in_tmp ^= 1u; ++executed; }
+        }
+        plan->result_in_tmp = in_tmp;
+        plan->executed = executed;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K3: one stable scatter pass.  grid = C * tiles_per_chain, block = NWAVES*64, one tile of
+// NWAVES*64*KPT keys per block, tile ids handed out by a per-chain ticket so that a tile's
+// predecessors have always started (forward progress of the look-back does not depend on
+// dispatch order).  blockIdx % C picks the chain: under the observed round-robin dispatch over
+// the 8 XCDs a chain's tiles then share one XCD (and its L2) when C == 8 — a speed property
+// only; every cross-workgroup word is an agent-scope relaxed atomic and the value carries its
+// own state bits, so no placement is assumed for correctness.
+// ------------------------------------------------------------------------------------------
+template <typename K, int KPT, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void onesweep_kernel(
+    K* __restrict__ buf_keys, K* __restrict__ buf_tmp, uint64_t n, int level, uint32_t C,
+    uint32_t tiles_per_chain, const uint64_t* __restrict__ base /* [C][256] of this level */,
+    uint32_t* __restrict__ status /* [C*tiles_per_chain][256] of this level */,
+    uint32_t* __restrict__ tickets /* [C] of this level */, const Plan* __restrict__ plan,
+    uint32_t* __restrict__ err, K neg, K pos) {
+    constexpr int BLOCK = NWAVES * 64;
+    constexpr int TILE = BLOCK * KPT;
+    static_assert(BLOCK >= RADIX, "need one thread per digit");
+
+    if (plan->skip[level]) return;
+    const bool from_tmp = plan->src_is_tmp[level] != 0;
+    const K* __restrict__ src = from_tmp ? buf_tmp : buf_keys;
+    K* __restrict__ dst = from_tmp ? buf_keys : buf_tmp;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* wave_hist = reinterpret_cast<uint32_t*>(smem);                          // [NWAVES][256]
+    uint64_t* s_delta = reinterpret_cast<uint64_t*>(smem + NWAVES * 1024);            // [256]
+    uint32_t* s_misc = reinterpret_cast<uint32_t*>(smem + NWAVES * 1024 + 2048);      // [16]
+    K* s_keys = reinterpret_cast<K*>(smem + NWAVES * 1024 + 2048 + 64);               // [TILE]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int shift = level * 8;
+    const uint32_t chain = blockIdx.x % C;
+
+    if (tid == 0) {
+        s_misc[0] = atomicAdd(&tickets[chain], 1u);
+        s_misc[1] = 0;  // block-wide failure flag
+    }
+    __syncthreads();
+    const uint32_t t = s_misc[0];
+    const uint64_t chain_len = (uint64_t)tiles_per_chain * TILE;
+    const uint64_t c_begin = (uint64_t)chain * chain_len;
+    if (c_begin >= n) return;
+    const uint64_t c_end = (c_begin + chain_len < n) ? c_begin + chain_len : n;
+    const uint64_t tile_begin = c_begin + (uint64_t)t * TILE;
+    if (tile_begin >= c_end) return;
+    const uint32_t valid = (c_end - tile_begin < (uint64_t)TILE) ? (uint32_t)(c_end - tile_begin) : (uint32_t)TILE;
+    uint32_t* row = status + ((size_t)chain * tiles_per_chain + t) * RADIX;
+
+    // 1. load, wave-striped: lane l of wave w takes keys w*64*KPT + i*64 + l (256 contiguous
+    //    bytes per wave-instruction for 4-byte keys), so index order == (wave, i, lane) order.
+    K mk[KPT];
+    {
+        const K* tsrc = src + tile_begin;
+        const uint32_t wbase = (uint32_t)wave * 64u * KPT + (uint32_t)lane;
+        if (valid == (uint32_t)TILE) {
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) mk[i] = tsrc[wbase + i * 64];
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) mk[i] = map_key<K>(mk[i], neg, pos);
+        } else {
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                const uint32_t idx = wbase + i * 64;
+                // out-of-range slots: mapped key all ones -> digit 255, ranked after every
+                // real key of the tile, never stored
+                mk[i] = (idx < valid) ? map_key<K>(tsrc[idx], neg, pos) : (K)~(K)0;
+            }
+        }
+    }
+
+    // 2. per-wave 256-bin histogram in LDS ("early counts")
+    uint32_t* wh = wave_hist + wave * RADIX;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wh[lane + 64 * j] = 0;
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) atomicAdd(&wh[digit_of(mk[i], shift)], 1u);
+    __syncthreads();
+
+    // 3. thread d: digit count over the block's waves; publish the tile aggregate at once
+    uint32_t cw[NWAVES];
+    uint32_t count_d = 0, pub = 0;
+    if (tid < RADIX) {
+#pragma unroll
+        for (int w = 0; w < NWAVES; ++w) {
+            cw[w] = wave_hist[w * RADIX + tid];
+            count_d += cw[w];
+        }
+        pub = count_d;
+        if (tid == RADIX - 1) pub -= (uint32_t)TILE - valid;  // sentinels are not keys
+        st_relaxed(&row[tid], ((t == 0 ? ST_INCL : ST_AGG) << 30) | pub);
+    }
+
+    // 4. exclusive scan of the 256 digit counts -> start of each digit's run inside the tile
+    uint32_t incl = count_d;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(incl, o);
+        if (lane >= o) incl += y;
+    }
+    if (tid < RADIX && lane == 63) s_misc[4 + wave] = incl;
+    __syncthreads();
+    uint32_t local_off = 0;
+    if (tid < RADIX) {
+        uint32_t woff = 0;
+        for (int w = 0; w < wave; ++w) woff += s_misc[4 + w];
+        local_off = woff + incl - count_d;
+        uint32_t run = local_off;
+#pragma unroll
+        for (int w = 0; w < NWAVES; ++w) {
+            wave_hist[w * RADIX + tid] = run;  // first slot of (wave w, digit d) inside the tile
+            run += cw[w];
+        }
+    }
+    __syncthreads();
+
+    // 5. stable rank inside the wave: lanes with my digit and a lower lane id go first;
+    //    rounds i go in order; the running slot lives in this wave's LDS row
+    uint32_t posn[KPT];
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+        const uint32_t d = digit_of(mk[i], shift);
+        const uint64_t peers = match_any8(d);
+        const uint32_t below = lanes_below(peers);
+        const uint32_t b = wh[d];
+        __builtin_amdgcn_wave_barrier();
+        if (below == 0) wh[d] = b + (uint32_t)__popcll(peers);
+        __builtin_amdgcn_wave_barrier();
+        posn[i] = b + below;
+    }
+
+    // 6. keys into LDS in tile-sorted order
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) s_keys[posn[i]] = mk[i];
+
+    // 7. decoupled look-back over this chain's earlier tiles (thread d walks digit d)
+    if (tid < RADIX) {
+        uint32_t excl = 0;
+        bool fail = false;
+        if (t > 0) {
+            const uint32_t* p = row - RADIX + tid;
+            uint32_t spins = 0;
+            for (;;) {
+                const uint32_t v = ld_relaxed(p);
+                const uint32_t st = v >> 30;
+                if (st == ST_EMPTY) {
+                    __builtin_amdgcn_s_sleep(2);
+                    ++spins;
+                    if (spins > SPIN_LIMIT || ((spins & 1023u) == 0 && ld_relaxed(err) != 0)) {
+                        fail = true;
+                        break;
+                    }
+                    continue;
+                }
+                excl += v & ST_VALUE_MASK;
+                if (st == ST_INCL) break;
+                p -= RADIX;  // tile 0 of a chain is always INCL, so this stays inside the chain
+            }
+            if (!fail) st_relaxed(&row[tid], (ST_INCL << 30) | ((excl + pub) & ST_VALUE_MASK));
+        }
+        if (fail) {
+            atomicOr(err, ERR_LOOKBACK_TIMEOUT);
+            s_misc[1] = 1;
+        }
+        s_delta[tid] = base[(size_t)chain * RADIX + tid] + (uint64_t)excl - (uint64_t)local_off;
+    }
+    __syncthreads();
+    if (s_misc[1]) return;  // never store with an unknown prefix
+
+    // 8. scatter: consecutive threads hold consecutive slots of a digit's run
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+        const uint32_t p = (uint32_t)tid + (uint32_t)i * BLOCK;
+        const K k = s_keys[p];
+        const uint32_t d = digit_of(k, shift);
+        if (p < valid) dst[s_delta[d] + p] = unmap_key<K>(k, neg, pos);
+    }
+}
+
+// result sits in tmp after an odd number of executed passes: copy back
+// (src/sorts/lsb_sort.rs:117-126)
+template <typename K, int VEC>
+__global__ __launch_bounds__(256) void copyback_kernel(K* __restrict__ keys, const K* __restrict__ tmp,
+                                                       uint64_t n, const Plan* __restrict__ plan) {
+    if (!plan->result_in_tmp) return;
+    struct alignas(sizeof(K) * VEC) V { K e[VEC]; };
+    const uint64_t nvec = n / VEC;
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride)
+        reinterpret_cast<V*>(keys)[i] = reinterpret_cast<const V*>(tmp)[i];
+    if (blockIdx.x == 0) {
+        const uint64_t i = nvec * VEC + threadIdx.x;
+        if (i < n) keys[i] = tmp[i];
+    }
+}
+
+// K6: one level's histogram + "digit sequence has an inversion" flag
+template <typename K>
+__global__ __launch_bounds__(256) void level_counts_kernel(const K* __restrict__ keys, uint64_t n, int shift,
+                                                           K neg, K pos, unsigned long long* __restrict__ counts,
+                                                           uint32_t* __restrict__ unsorted) {
+    __shared__ uint32_t s_h[RADIX];
+    __shared__ uint32_t s_uns;
+    s_h[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_uns = 0;
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    bool uns = false;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const uint32_t d = digit_of(map_key<K>(keys[i], neg, pos), shift);
+        if (i > 0) {
+            const uint32_t dp = digit_of(map_key<K>(keys[i - 1], neg, pos), shift);
+            uns |= d < dp;
+        }
+        atomicAdd(&s_h[d], 1u);
+    }
+    if (uns) s_uns = 1;
+    __syncthreads();
+    if (s_h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)s_h[threadIdx.x]);
+    if (threadIdx.x == 0 && s_uns) atomicOr(unsorted, 1u);
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+thread_local std::string g_last_error;
+
+int fail(int code, const char* what, hipError_t e = hipSuccess) {
+    char buf[512];
+    if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    else snprintf(buf, sizeof buf, "%s", what);
+    g_last_error = buf;
+    return code;
+}
+#define HIP_TRY(expr)                                                   \
+    do {                                                                \
+        hipError_t e__ = (expr);                                        \
+        if (e__ != hipSuccess) return fail(RDST_ERR_HIP, #expr, e__);   \
+    } while (0)
+
+struct PassCfg { int nwaves, kpt4, kpt8; };
+constexpr PassCfg kPassCfgs[] = {
+    {8, 16, 8},    // 0: 512 threads, 8192 / 4096 keys per tile (32 KiB of keys)
+    {16, 16, 8},   // 1: 1024 threads, 16384 / 8192
+    {4, 16, 8},    // 2: 256 threads, 4096 / 2048
+    {8, 24, 12},   // 3: 512 threads, 12288 / 6144
+};
+constexpr int kNumPassCfgs = sizeof(kPassCfgs) / sizeof(kPassCfgs[0]);
+
+struct Tuning { int chains = 0; int pass_cfg = 0; int hist_bpc = 0; };
+Tuning g_tuning;
+std::mutex g_mutex;
+
+struct DeviceState {
+    bool init = false;
+    int cus = 256;
+    void* ws = nullptr;
+    size_t ws_bytes = 0;
+    uint32_t* host_err = nullptr;  // pinned
+    hipEvent_t last_done = nullptr;  // recorded after every enqueue that uses the workspace
+    hipStream_t last_stream = nullptr;
+    bool have_last = false;
+};
+DeviceState g_dev[16];
+
+struct Layout {
+    uint32_t C, tiles_per_chain, levels, tile;
+    uint64_t chain_len;
+    size_t off_err, off_tickets, off_plan, off_hist, off_status, zero_bytes, off_base, off_totals, total;
+};
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+int tile_keys(int cfg, uint32_t elem_bytes) {
+    const PassCfg& p = kPassCfgs[cfg];
+    return p.nwaves * 64 * (elem_bytes == 8 ? p.kpt8 : p.kpt4);
+}
+
+Layout make_layout(uint64_t n, uint32_t elem_bytes, uint32_t levels, int cfg, int chains_pref) {
+    Layout L{};
+    L.levels = levels;
+    L.tile = (uint32_t)tile_keys(cfg, elem_bytes);
+    const uint64_t total_tiles = (n + L.tile - 1) / L.tile;
+    // a chain's inclusive prefix must fit 30 bits
+    const uint64_t max_chain_tiles = ((1ull << 30) - 1) / L.tile;
+    uint64_t C = chains_pref > 0 ? (uint64_t)chains_pref : 8;
+    if (total_tiles < 64 * C) C = 1;  // small inputs: one chain
+    uint64_t need = (total_tiles + max_chain_tiles - 1) / max_chain_tiles;
+    if (C < need) C = need;
+    if (C > MAX_CHAINS) C = MAX_CHAINS;
+    if (C < 1) C = 1;
+    L.C = (uint32_t)C;
+    L.tiles_per_chain = (uint32_t)((total_tiles + C - 1) / C);
+    if (L.tiles_per_chain == 0) L.tiles_per_chain = 1;
+    L.chain_len = (uint64_t)L.tiles_per_chain * L.tile;
+    size_t o = 0;
+    L.off_err = o; o += 16;
+    L.off_tickets = o; o += sizeof(uint32_t) * MAX_LEVELS * MAX_CHAINS;
+    L.off_plan = o; o += align_up(sizeof(Plan), 16);
+    L.off_hist = o; o += sizeof(uint32_t) * (size_t)L.C * levels * RADIX;
+    L.off_status = o; o += sizeof(uint32_t) * (size_t)levels * L.C * L.tiles_per_chain * RADIX;
+    L.zero_bytes = align_up(o, 16); o = L.zero_bytes;
+    L.off_base = o; o += sizeof(uint64_t) * (size_t)levels * L.C * RADIX;
+    L.off_totals = o; o += sizeof(uint64_t) * (size_t)levels * RADIX;
+    L.total = align_up(o, 256);
+    return L;
+}
+
+int current_device_state(DeviceState** out, int* dev_out = nullptr) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail(RDST_ERR_NO_DEVICE, "hipGetDevice", e);
+    if (dev < 0 || dev >= 16) return fail(RDST_ERR_NO_DEVICE, "device ordinal out of range");
+    DeviceState& D = g_dev[dev];
+    if (!D.init) {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, dev));
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            char b[160];
+            snprintf(b, sizeof b, "device %d is %s; this library is built for gfx950 only", dev, prop.gcnArchName);
+            return fail(RDST_ERR_NO_DEVICE, b);
+        }
+        D.cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        HIP_TRY(hipHostMalloc((void**)&D.host_err, 64, hipHostMallocDefault));
+        HIP_TRY(hipEventCreateWithFlags(&D.last_done, hipEventDisableTiming));
+        D.init = true;
+    }
+    *out = &D;
+    if (dev_out) *dev_out = dev;
+    return RDST_OK;
+}
+
+int ensure_workspace(DeviceState& D, size_t bytes) {
+    if (D.ws_bytes >= bytes) return RDST_OK;
+    if (D.ws) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipFree(D.ws));
+        D.ws = nullptr;
+        D.ws_bytes = 0;
+    }
+    const size_t want = align_up(bytes + bytes / 8, 1 << 20);
+    HIP_TRY(hipMalloc(&D.ws, want));
+    D.ws_bytes = want;
+    return RDST_OK;
+}
+
+// The workspace is shared by every call on the device: work queued on another stream must
+// finish before this stream reuses it.
+int workspace_acquire(DeviceState& D, hipStream_t s) {
+    if (D.have_last && D.last_stream != s) HIP_TRY(hipStreamWaitEvent(s, D.last_done, 0));
+    return RDST_OK;
+}
+int workspace_release(DeviceState& D, hipStream_t s) {
+    HIP_TRY(hipEventRecord(D.last_done, s));
+    D.last_stream = s;
+    D.have_last = true;
+    return RDST_OK;
+}
+
+KeyMap key_map_for(rdst_key_kind kind, uint32_t elem_bytes) {
+    const uint64_t msb = 1ull << (elem_bytes * 8 - 1);
+    const uint64_t ones = elem_bytes == 8 ? ~0ull : ((1ull << (elem_bytes * 8)) - 1);
+    switch (kind) {
+        case RDST_KEY_SIGNED: return {msb, msb};
+        case RDST_KEY_FLOAT: return {ones, msb};
+        default: return {0, 0};
+    }
+}
+
+template <typename K, int LEVELS>
+int launch_hist(const K* keys, uint64_t n, const Layout& L, uint32_t bpc, KeyMap km, uint32_t* hist, hipStream_t s) {
+    const dim3 grid(L.C * bpc), block(256);
+    const bool aligned = (reinterpret_cast<uintptr_t>(keys) & 15u) == 0;
+    constexpr int VEC = 16 / sizeof(K);
+    if (aligned)
+        hipLaunchKernelGGL((hist_kernel<K, LEVELS, VEC>), grid, block, 0, s, keys, n, L.chain_len, bpc, (K)km.neg, (K)km.pos, hist);
+    else
+        hipLaunchKernelGGL((hist_kernel<K, LEVELS, 1>), grid, block, 0, s, keys, n, L.chain_len, bpc, (K)km.neg, (K)km.pos, hist);
+    HIP_TRY(hipGetLastError());
+    return RDST_OK;
+}
+
+template <typename K, int KPT, int NWAVES>
+int launch_pass_t(K* keys, K* tmp, uint64_t n, int level, const Layout& L, char* ws, KeyMap km, hipStream_t s) {
+    constexpr int TILE = NWAVES * 64 * KPT;
+    const size_t lds = (size_t)NWAVES * 1024 + 2048 + 64 + sizeof(K) * TILE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&onesweep_kernel<K, KPT, NWAVES>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const uint64_t* base = reinterpret_cast<const uint64_t*>(ws + L.off_base) + (size_t)level * L.C * RADIX;
+    uint32_t* status = reinterpret_cast<uint32_t*>(ws + L.off_status) + (size_t)level * L.C * L.tiles_per_chain * RADIX;
+    uint32_t* tickets = reinterpret_cast<uint32_t*>(ws + L.off_tickets) + (size_t)level * MAX_CHAINS;
+    const Plan* plan = reinterpret_cast<const Plan*>(ws + L.off_plan);
+    uint32_t* err = reinterpret_cast<uint32_t*>(ws + L.off_err);
+    const dim3 grid(L.C * L.tiles_per_chain), block(NWAVES * 64);
+    hipLaunchKernelGGL((onesweep_kernel<K, KPT, NWAVES>), grid, block, lds, s, keys, tmp, n, level, L.C,
+                       L.tiles_per_chain, base, status, tickets, plan, err, (K)km.neg, (K)km.pos);
+    HIP_TRY(hipGetLastError());
+    return RDST_OK;
+}
+
+template <typename K>
+int launch_pass(int cfg, K* keys, K* tmp, uint64_t n, int level, const Layout& L, char* ws, KeyMap km, hipStream_t s) {
+    if constexpr (sizeof(K) == 4) {
+        switch (cfg) {
+            case 0: return launch_pass_t<K, 16, 8>(keys, tmp, n, level, L, ws, km, s);
+            case 1: return launch_pass_t<K, 16, 16>(keys, tmp, n, level, L, ws, km, s);
+            case 2: return launch_pass_t<K, 16, 4>(keys, tmp, n, level, L, ws, km, s);
+            case 3: return launch_pass_t<K, 24, 8>(keys, tmp, n, level, L, ws, km, s);
+        }
+    } else {
+        switch (cfg) {
+            case 0: return launch_pass_t<K, 8, 8>(keys, tmp, n, level, L, ws, km, s);
+            case 1: return launch_pass_t<K, 8, 16>(keys, tmp, n, level, L, ws, km, s);
+            case 2: return launch_pass_t<K, 8, 4>(keys, tmp, n, level, L, ws, km, s);
+            case 3: return launch_pass_t<K, 12, 8>(keys, tmp, n, level, L, ws, km, s);
+        }
+    }
+    return fail(RDST_ERR_ARG, "bad pass config");
+}
+
+// The whole device-side pipeline for levels [level_lo, level_hi): memset, K1, K2, passes,
+// optional copy-back.  `allow_skip` turns on level skipping.  With copy_back == false the
+// caller reads Plan::result_in_tmp itself (scatter hook).
+template <typename K, int LEVELS>
+int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level_lo, uint32_t level_hi,
+                 bool allow_skip, bool copy_back, hipStream_t s, Layout* layout_out, char** ws_out) {
+    DeviceState* D;
+    int rc = current_device_state(&D);
+    if (rc) return rc;
+    int cfg = g_tuning.pass_cfg;
+    if (cfg < 0 || cfg >= kNumPassCfgs) cfg = 0;
+    const Layout L = make_layout(n, sizeof(K), LEVELS, cfg, g_tuning.chains);
+    rc = ensure_workspace(*D, L.total);
+    if (rc) return rc;
+    char* ws = static_cast<char*>(D->ws);
+    const KeyMap km = key_map_for(kind, sizeof(K));
+    rc = workspace_acquire(*D, s);
+    if (rc) return rc;
+
+    HIP_TRY(hipMemsetAsync(ws, 0, L.zero_bytes, s));
+    // K1: enough blocks to fill the chip several times over, but no more than the data needs
+    uint32_t bpc_pref = (uint32_t)((g_tuning.hist_bpc > 0 ? g_tuning.hist_bpc : 8) * D->cus);
+    uint32_t bpc = (bpc_pref + L.C - 1) / L.C;
+    const uint64_t per_block_min = 256ull * (16 / sizeof(K)) * 4;
+    const uint64_t max_useful = (L.chain_len + per_block_min - 1) / per_block_min;
+    if (bpc > max_useful) bpc = (uint32_t)max_useful;
+    if (bpc < 1) bpc = 1;
+    uint32_t* hist = reinterpret_cast<uint32_t*>(ws + L.off_hist);
+    rc = launch_hist<K, LEVELS>(keys, n, L, bpc, km, hist, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(256), 0, s, hist, reinterpret_cast<uint64_t*>(ws + L.off_base),
+                       reinterpret_cast<Plan*>(ws + L.off_plan), reinterpret_cast<uint64_t*>(ws + L.off_totals),
+                       L.C, (uint32_t)LEVELS, n, allow_skip ? 1u : 0u, level_lo, level_hi);
+    HIP_TRY(hipGetLastError());
+    for (uint32_t level = level_lo; level < level_hi; ++level) {
+        rc = launch_pass<K>(cfg, keys, tmp, n, (int)level, L, ws, km, s);
+        if (rc) return rc;
+    }
+    if (copy_back) {
+        const bool aligned = ((reinterpret_cast<uintptr_t>(keys) | reinterpret_cast<uintptr_t>(tmp)) & 15u) == 0;
+        uint64_t blocks = (n * sizeof(K) / 16 + 255) / 256;
+        const uint64_t cap = (uint64_t)D->cus * 16;
+        if (blocks > cap) blocks = cap;
+        if (blocks < 1) blocks = 1;
+        const Plan* plan = reinterpret_cast<const Plan*>(ws + L.off_plan);
+        constexpr int VEC = 16 / sizeof(K);
+        if (aligned)
+            hipLaunchKernelGGL((copyback_kernel<K, VEC>), dim3((uint32_t)blocks), dim3(256), 0, s, keys, tmp, n, plan);
+        else
+            hipLaunchKernelGGL((copyback_kernel<K, 1>), dim3((uint32_t)blocks), dim3(256), 0, s, keys, tmp, n, plan);
+        HIP_TRY(hipGetLastError());
+    }
+    if (layout_out) *layout_out = L;
+    if (ws_out) *ws_out = ws;
+    return workspace_release(*D, s);
+}
+
+int check_common(const void* p, uint64_t len, uint32_t elem_bytes, rdst_key_kind kind, uint32_t levels) {
+    if (elem_bytes != 4 && elem_bytes != 8) return fail(RDST_ERR_UNSUPPORTED, "device path is built for 4- and 8-byte keys");
+    if (levels == 0) return fail(RDST_ERR_ARG, "RadixKey must have at least 1 level");
+    if (levels != elem_bytes) return fail(RDST_ERR_ARG, "levels must equal the element width for built-in key types");
+    if ((int)kind < 0 || (int)kind > 2) return fail(RDST_ERR_ARG, "unknown key kind");
+    if (len > 0 && p == nullptr) return fail(RDST_ERR_ARG, "null key pointer");
+    if (reinterpret_cast<uintptr_t>(p) % elem_bytes) return fail(RDST_ERR_ALIGN, "key pointer not aligned to the element size");
+    if (len >= (1ull << 36)) return fail(RDST_ERR_ARG, "len too large");
+    return RDST_OK;
+}
+
+int read_device_error(DeviceState& D, hipStream_t s) {
+    if (!D.ws) return RDST_OK;
+    HIP_TRY(hipMemcpyAsync(D.host_err, D.ws, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (*D.host_err != 0) {
+        char b[128];
+        snprintf(b, sizeof b, "device error word = 0x%x (look-back spin bound expired)", *D.host_err);
+        return fail(RDST_ERR_DEVICE, b);
+    }
+    return RDST_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* rdst_hip_last_error(void) { return g_last_error.c_str(); }
+int rdst_hip_abi_version(void) { return RDST_HIP_ABI_VERSION; }
+
+int rdst_hip_set_tuning(int chains, int pass_config, int hist_blocks_per_cu) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    if (chains > MAX_CHAINS || pass_config >= kNumPassCfgs) return fail(RDST_ERR_ARG, "tuning value out of range");
+    g_tuning.chains = chains > 0 ? chains : 0;
+    g_tuning.pass_cfg = pass_config > 0 ? pass_config : 0;
+    g_tuning.hist_bpc = hist_blocks_per_cu > 0 ? hist_blocks_per_cu : 0;
+    return RDST_OK;
+}
+
+uint64_t rdst_hip_workspace_bytes(uint64_t len, uint32_t elem_bytes) {
+    if (elem_bytes != 4 && elem_bytes != 8) return 0;
+    int cfg = g_tuning.pass_cfg;
+    return make_layout(len, elem_bytes, elem_bytes, cfg, g_tuning.chains).total;
+}
+
+int rdst_hip_sort_device(void* dev_keys, void* dev_tmp, uint64_t len, uint32_t elem_bytes, rdst_key_kind kind,
+                         uint32_t levels, void* stream) {
+    int rc = check_common(dev_keys, len, elem_bytes, kind, levels);
+    if (rc) return rc;
+    if (len <= 1) return RDST_OK;  // radix_sort_builder.rs:151
+    if (dev_tmp == nullptr) return fail(RDST_ERR_ARG, "null tmp pointer");
+    if (reinterpret_cast<uintptr_t>(dev_tmp) % elem_bytes) return fail(RDST_ERR_ALIGN, "tmp pointer not aligned to the element size");
+    std::lock_guard<std::mutex> lock(g_mutex);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (elem_bytes == 4)
+        return run_pipeline<uint32_t, 4>(static_cast<uint32_t*>(dev_keys), static_cast<uint32_t*>(dev_tmp), len, kind, 0, 4, true, true, s, nullptr, nullptr);
+    return run_pipeline<uint64_t, 8>(static_cast<uint64_t*>(dev_keys), static_cast<uint64_t*>(dev_tmp), len, kind, 0, 8, true, true, s, nullptr, nullptr);
+}
+
+int rdst_hip_device_status(void* stream) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    DeviceState* D;
+    int rc = current_device_state(&D);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipStreamSynchronize(s));
+    return read_device_error(*D, s);
+}
+
+int rdst_hip_sort(void* host_data, uint64_t len, uint32_t elem_bytes, rdst_key_kind kind, uint32_t levels,
+                  const rdst_hip_opts* opts) {
+    int rc = check_common(host_data, len, elem_bytes, kind, levels);
+    if (rc) return rc;
+    if (len <= 1) return RDST_OK;
+    int prev_dev = -1;
+    if (opts && opts->device >= 0) {
+        HIP_TRY(hipGetDevice(&prev_dev));
+        HIP_TRY(hipSetDevice(opts->device));
+    }
+    const size_t bytes = (size_t)len * elem_bytes;
+    void *d_keys = nullptr, *d_tmp = nullptr;
+    hipStream_t s = nullptr;
+    auto cleanup = [&]() {
+        if (d_keys) (void)hipFree(d_keys);
+        if (d_tmp) (void)hipFree(d_tmp);
+        if (s) (void)hipStreamDestroy(s);
+        if (prev_dev >= 0) (void)hipSetDevice(prev_dev);
+    };
+    hipError_t e;
+    if ((e = hipStreamCreate(&s)) != hipSuccess) { cleanup(); return fail(RDST_ERR_HIP, "hipStreamCreate", e); }
+    if ((e = hipMalloc(&d_keys, bytes)) != hipSuccess) { cleanup(); return fail(RDST_ERR_HIP, "hipMalloc(keys)", e); }
+    if ((e = hipMalloc(&d_tmp, bytes)) != hipSuccess) { cleanup(); return fail(RDST_ERR_HIP, "hipMalloc(tmp)", e); }
+    if ((e = hipMemcpyAsync(d_keys, host_data, bytes, hipMemcpyHostToDevice, s)) != hipSuccess) { cleanup(); return fail(RDST_ERR_HIP, "H2D", e); }
+    rc = rdst_hip_sort_device(d_keys, d_tmp, len, elem_bytes, kind, levels, s);
+    if (rc == RDST_OK) rc = rdst_hip_device_status(s);
+    if (rc != RDST_OK) { (void)hipStreamSynchronize(s); cleanup(); return rc; }
+    // the host buffer is written only now, after the device reported success
+    if ((e = hipMemcpyAsync(host_data, d_keys, bytes, hipMemcpyDeviceToHost, s)) != hipSuccess) { cleanup(); return fail(RDST_ERR_HIP, "D2H", e); }
+    if ((e = hipStreamSynchronize(s)) != hipSuccess) { cleanup(); return fail(RDST_ERR_HIP, "sync", e); }
+    cleanup();
+    return RDST_OK;
+}
+
+int rdst_hip_all_level_counts(const void* dev_keys, uint64_t len, uint32_t elem_bytes, rdst_key_kind kind,
+                              uint32_t levels, uint64_t* counts_out, void* stream) {
+    int rc = check_common(dev_keys, len, elem_bytes, kind, levels);
+    if (rc) return rc;
+    if (!counts_out) return fail(RDST_ERR_ARG, "null counts_out");
+    memset(counts_out, 0, sizeof(uint64_t) * levels * RADIX);
+    if (len == 0) return RDST_OK;
+    std::lock_guard<std::mutex> lock(g_mutex);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Layout L;
+    char* ws = nullptr;
+    // levels [0,0): histogram + scan only, no pass runs
+    if (elem_bytes == 4)
+        rc = run_pipeline<uint32_t, 4>(const_cast<uint32_t*>(static_cast<const uint32_t*>(dev_keys)), nullptr, len, kind, 0, 0, false, false, s, &L, &ws);
+    else
+        rc = run_pipeline<uint64_t, 8>(const_cast<uint64_t*>(static_cast<const uint64_t*>(dev_keys)), nullptr, len, kind, 0, 0, false, false, s, &L, &ws);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(counts_out, ws + L.off_totals, sizeof(uint64_t) * levels * RADIX, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return RDST_OK;
+}
+
+int rdst_hip_scatter_level(const void* dev_src, void* dev_dst, uint64_t len, uint32_t elem_bytes, rdst_key_kind kind,
+                           uint32_t level, uint64_t* counts_out, void* stream) {
+    int rc = check_common(dev_src, len, elem_bytes, kind, elem_bytes);
+    if (rc) return rc;
+    if (level >= elem_bytes) return fail(RDST_ERR_ARG, "level out of range");
+    if (counts_out) memset(counts_out, 0, sizeof(uint64_t) * RADIX);
+    if (len == 0) return RDST_OK;
+    if (dev_dst == nullptr) return fail(RDST_ERR_ARG, "null dst pointer");
+    if (reinterpret_cast<uintptr_t>(dev_dst) % elem_bytes) return fail(RDST_ERR_ALIGN, "dst pointer not aligned to the element size");
+    std::lock_guard<std::mutex> lock(g_mutex);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Layout L;
+    char* ws = nullptr;
+    // one un-skippable pass keys -> tmp, no copy-back: src is only read
+    if (elem_bytes == 4)
+        rc = run_pipeline<uint32_t, 4>(const_cast<uint32_t*>(static_cast<const uint32_t*>(dev_src)), static_cast<uint32_t*>(dev_dst), len, kind, level, level + 1, false, false, s, &L, &ws);
+    else
+        rc = run_pipeline<uint64_t, 8>(const_cast<uint64_t*>(static_cast<const uint64_t*>(dev_src)), static_cast<uint64_t*>(dev_dst), len, kind, level, level + 1, false, false, s, &L, &ws);
+    if (rc) return rc;
+    if (counts_out)
+        HIP_TRY(hipMemcpyAsync(counts_out, ws + L.off_totals + sizeof(uint64_t) * (size_t)level * RADIX, sizeof(uint64_t) * RADIX, hipMemcpyDeviceToHost, s));
+    DeviceState* D;
+    rc = current_device_state(&D);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(s));
+    return read_device_error(*D, s);
+}
+
+int rdst_hip_level_counts(const void* dev_keys, uint64_t len, uint32_t elem_bytes, rdst_key_kind kind, uint32_t level,
+                          uint64_t counts[256], uint8_t* already_sorted, uint8_t* first_digit, uint8_t* last_digit,
+                          void* stream) {
+    int rc = check_common(dev_keys, len, elem_bytes, kind, elem_bytes);
+    if (rc) return rc;
+    if (level >= elem_bytes) return fail(RDST_ERR_ARG, "level out of range");
+    if (!counts) return fail(RDST_ERR_ARG, "null counts");
+    memset(counts, 0, sizeof(uint64_t) * RADIX);
+    if (already_sorted) *already_sorted = 1;
+    if (first_digit) *first_digit = 0;
+    if (last_digit) *last_digit = 0;
+    if (len == 0) return RDST_OK;  // sort_utils.rs:116-118
+    std::lock_guard<std::mutex> lock(g_mutex);
+    DeviceState* D;
+    rc = current_device_state(&D);
+    if (rc) return rc;
+    rc = ensure_workspace(*D, 1 << 20);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    char* ws = static_cast<char*>(D->ws);
+    // scratch inside the workspace head: 256 u64 counts + flag
+    unsigned long long* d_counts = reinterpret_cast<unsigned long long*>(ws + 4096);
+    uint32_t* d_flag = reinterpret_cast<uint32_t*>(ws + 4096 + sizeof(uint64_t) * RADIX);
+    rc = workspace_acquire(*D, s);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(d_counts, 0, sizeof(uint64_t) * RADIX + 16, s));
+    const KeyMap km = key_map_for(kind, elem_bytes);
+    uint64_t blocks = (len + 255) / 256;
+    const uint64_t cap = (uint64_t)D->cus * 8;
+    if (blocks > cap) blocks = cap;
+    const int shift = (int)level * 8;
+    if (elem_bytes == 4)
+        hipLaunchKernelGGL((level_counts_kernel<uint32_t>), dim3((uint32_t)blocks), dim3(256), 0, s, static_cast<const uint32_t*>(dev_keys), len, shift, (uint32_t)km.neg, (uint32_t)km.pos, d_counts, d_flag);
+    else
+        hipLaunchKernelGGL((level_counts_kernel<uint64_t>), dim3((uint32_t)blocks), dim3(256), 0, s, static_cast<const uint64_t*>(dev_keys), len, shift, (uint64_t)km.neg, (uint64_t)km.pos, d_counts, d_flag);
+    HIP_TRY(hipGetLastError());
+    uint32_t flag = 0;
+    uint64_t first = 0, last = 0;
+    HIP_TRY(hipMemcpyAsync(counts, d_counts, sizeof(uint64_t) * RADIX, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&flag, d_flag, sizeof flag, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&first, dev_keys, elem_bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&last, static_cast<const char*>(dev_keys) + (len - 1) * elem_bytes, elem_bytes, hipMemcpyDeviceToHost, s));
+    rc = workspace_release(*D, s);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(s));
+    auto host_digit = [&](uint64_t raw) -> uint8_t {
+        const uint64_t sign = raw >> (elem_bytes * 8 - 1) & 1;
+        const uint64_t m = raw ^ (sign ? km.neg : km.pos);
+        return (uint8_t)(m >> shift);
+    };
+    if (already_sorted) *already_sorted = flag ? 0 : 1;
+    if (first_digit) *first_digit = host_digit(first);
+    if (last_digit) *last_digit = host_digit(last);
+    return RDST_OK;
+}
+
+}  // extern "C"

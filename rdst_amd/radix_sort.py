@@ -1,0 +1,224 @@
+"""Host mirror of rdst's entry points for the device route.
+
+Reference surface (paths in the reference tree):
+  * ``RadixSort::radix_sort_unstable`` / ``radix_sort_builder``   src/radix_sort.rs:4-45
+  * ``RadixSortBuilder`` and its ``with_*`` methods / ``sort``     src/radix_sort_builder.rs:8-158
+  * ``RadixKey`` built-in mappings -> (kind, elem_bytes, levels)   src/radix_key_impl.rs:1-185
+
+Accepted containers: a C-contiguous 1-D ``numpy.ndarray`` (host slice -> ``rdst_hip_sort``)
+or a contiguous 1-D ``torch.Tensor`` on a HIP device (device slice ->
+``rdst_hip_sort_device``; PyTorch only provides the memory and the stream).  Sorting is in
+place, returns ``None`` like the reference, and raises instead of falling back when the
+device path is unavailable: this package ships the device route only — the CPU algorithms
+remain the reference crate's own.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .tuner import Algorithm, GpuTuner, LowMemoryTuner, SingleThreadedTuner, Tuner, TuningParams
+
+# dtype name -> (rdst_key_kind, elem_bytes); LEVELS == elem_bytes for every built-in type
+_KEY_TABLE = {
+    "uint32": (_lib.RDST_KEY_UNSIGNED, 4),
+    "uint64": (_lib.RDST_KEY_UNSIGNED, 8),
+    "int32": (_lib.RDST_KEY_SIGNED, 4),
+    "int64": (_lib.RDST_KEY_SIGNED, 8),
+    "float32": (_lib.RDST_KEY_FLOAT, 4),
+    "float64": (_lib.RDST_KEY_FLOAT, 8),
+}
+
+
+def key_info(dtype_name: str):
+    """(kind, elem_bytes, levels) of a built-in RadixKey (src/radix_key_impl.rs)."""
+    name = str(dtype_name).replace("torch.", "")
+    if name not in _KEY_TABLE:
+        raise TypeError(f"no device RadixKey mapping for dtype {dtype_name}; supported: {sorted(_KEY_TABLE)}")
+    kind, nbytes = _KEY_TABLE[name]
+    return kind, nbytes, nbytes
+
+
+def _is_torch_tensor(x):
+    return type(x).__module__.startswith("torch") and hasattr(x, "data_ptr")
+
+
+def _stream_handle(tensor):
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream(tensor.device).cuda_stream)
+
+
+def sort_device_tensor(keys, tmp=None, check=True):
+    """``rdst_hip_sort_device`` on a 1-D contiguous HIP tensor.  ``tmp``: optional scratch
+    tensor of the same shape/dtype (allocated when omitted).  With ``check`` the call blocks
+    and raises if a kernel reported failure; without it the sort stays asynchronous on the
+    tensor's current stream (call :func:`device_status` later)."""
+    import torch
+    if not keys.is_cuda:
+        raise ValueError("sort_device_tensor needs a tensor on a HIP device")
+    if keys.dim() != 1 or not keys.is_contiguous():
+        raise ValueError("keys must be a contiguous 1-D tensor (rdst sorts a slice)")
+    kind, nbytes, levels = key_info(keys.dtype)
+    n = keys.numel()
+    if n <= 1:
+        return
+    if tmp is None:
+        tmp = torch.empty_like(keys)
+    elif tmp.dtype != keys.dtype or tmp.numel() < n or not tmp.is_contiguous() or tmp.device != keys.device:
+        raise ValueError("tmp must be a contiguous tensor of the same dtype/device with at least len elements")
+    lib = _lib.load()
+    with torch.cuda.device(keys.device):
+        s = _stream_handle(keys)
+        _lib.check(lib.rdst_hip_sort_device(ctypes.c_void_p(keys.data_ptr()), ctypes.c_void_p(tmp.data_ptr()),
+                                            n, nbytes, kind, levels, s))
+        if check:
+            _lib.check(lib.rdst_hip_device_status(s))
+
+
+def device_status(device=None):
+    """Block on the current stream and raise if a kernel reported failure."""
+    import torch
+    lib = _lib.load()
+    with torch.cuda.device(device):
+        _lib.check(lib.rdst_hip_device_status(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+
+def sort_host_array(arr, device=-1):
+    """``rdst_hip_sort`` on a host numpy array (H2D, device sort, D2H), in place."""
+    if not isinstance(arr, np.ndarray) or arr.ndim != 1 or not arr.flags.c_contiguous or not arr.flags.writeable:
+        raise ValueError("need a writeable C-contiguous 1-D numpy array (rdst sorts a mutable slice)")
+    kind, nbytes, levels = key_info(arr.dtype.name)
+    if arr.size <= 1:
+        return
+    lib = _lib.load()
+    opts = _lib.HipOptsC(int(device), 0, 0)
+    _lib.check(lib.rdst_hip_sort(ctypes.c_void_p(arr.ctypes.data), arr.size, nbytes, kind, levels, ctypes.byref(opts)))
+
+
+class RadixSortBuilder:
+    """src/radix_sort_builder.rs:8-158.  ``with_parallel`` and the CPU tuners are accepted for
+    source compatibility; they select among the reference's CPU algorithms, which this package
+    does not ship, so on the device route they only take part in the top-level
+    ``pick_algorithm`` call (a tuner that does not return a ``Gpu*`` algorithm raises)."""
+
+    def __init__(self, data):
+        self._data = data
+        self._multi_threaded = True
+        self._tuner: Tuner = GpuTuner(0)
+
+    def with_parallel(self, parallel: bool):
+        self._multi_threaded = bool(parallel)
+        return self
+
+    def with_low_mem_tuner(self):
+        self._tuner = LowMemoryTuner()
+        return self
+
+    def with_single_threaded_tuner(self):
+        self._tuner = SingleThreadedTuner()
+        return self
+
+    def with_tuner(self, tuner: Tuner):
+        if not hasattr(tuner, "pick_algorithm"):
+            raise TypeError("tuner must implement pick_algorithm(p, counts)")
+        self._tuner = tuner
+        return self
+
+    def _len_and_levels(self):
+        d = self._data
+        if _is_torch_tensor(d):
+            return d.numel(), key_info(d.dtype)[2]
+        return d.size, key_info(d.dtype.name)[2]
+
+    def sort(self):
+        n, levels = self._len_and_levels()
+        if n <= 1:  # radix_sort_builder.rs:151
+            return
+        if not isinstance(self._tuner, GpuTuner):
+            # top-level pick_algorithm, as Sorter::handle_chunk does (src/sorter.rs:67-76)
+            counts = top_level_counts(self._data)
+            algo = self._tuner.pick_algorithm(
+                TuningParams(threads=1, level=levels - 1, total_levels=levels, input_len=n, parent_len=None), counts)
+            if algo not in (Algorithm.GpuLsd, Algorithm.GpuSharded):
+                raise NotImplementedError(
+                    f"tuner picked {Algorithm(algo).name}: the CPU algorithms stay in the reference crate; "
+                    "this package implements the device route (Algorithm.GpuLsd) only")
+        if _is_torch_tensor(self._data):
+            sort_device_tensor(self._data)
+        else:
+            sort_host_array(self._data)
+
+
+def top_level_counts(data):
+    """256-bin histogram of the most significant level (what handle_chunk hands the tuner)."""
+    import torch
+    if _is_torch_tensor(data):
+        dev = data
+    else:
+        dev = torch.from_numpy(data.view(_same_width_int(data.dtype))).cuda()
+        dev = dev.view(getattr(torch, data.dtype.name))
+    counts, _, _, _ = level_counts(dev, key_info(dev.dtype)[2] - 1)
+    return counts
+
+
+def _same_width_int(dt):
+    return {4: np.int32, 8: np.int64}[np.dtype(dt).itemsize]
+
+
+def level_counts(keys, level):
+    """Parity hook: (counts[256], already_sorted, first_digit, last_digit) of one level
+    (get_counts_with_ends, src/sort_utils.rs:109-180) over a HIP tensor."""
+    kind, nbytes, _ = key_info(keys.dtype)
+    lib = _lib.load()
+    counts = (ctypes.c_uint64 * 256)()
+    srt, first, last = ctypes.c_uint8(1), ctypes.c_uint8(0), ctypes.c_uint8(0)
+    import torch
+    with torch.cuda.device(keys.device):
+        _lib.check(lib.rdst_hip_level_counts(ctypes.c_void_p(keys.data_ptr()), keys.numel(), nbytes, kind, level,
+                                             counts, ctypes.byref(srt), ctypes.byref(first), ctypes.byref(last),
+                                             _stream_handle(keys)))
+    return list(counts), bool(srt.value), first.value, last.value
+
+
+def all_level_counts(keys):
+    """Parity hook for the fused histogram kernel: numpy uint64 array [levels, 256]."""
+    kind, nbytes, levels = key_info(keys.dtype)
+    lib = _lib.load()
+    out = np.zeros((levels, 256), dtype=np.uint64)
+    import torch
+    with torch.cuda.device(keys.device):
+        _lib.check(lib.rdst_hip_all_level_counts(ctypes.c_void_p(keys.data_ptr()), keys.numel(), nbytes, kind, levels,
+                                                 out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), _stream_handle(keys)))
+    return out
+
+
+def scatter_level(src, level, dst=None):
+    """Parity hook: one stable counting-sort pass on digit ``level`` (out_of_place_sort,
+    src/sorts/out_of_place_sort.rs:52-108).  Returns (dst tensor, counts[256])."""
+    import torch
+    kind, nbytes, _ = key_info(src.dtype)
+    lib = _lib.load()
+    if dst is None:
+        dst = torch.empty_like(src)
+    counts = np.zeros(256, dtype=np.uint64)
+    with torch.cuda.device(src.device):
+        _lib.check(lib.rdst_hip_scatter_level(ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(dst.data_ptr()),
+                                              src.numel(), nbytes, kind, level,
+                                              counts.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), _stream_handle(src)))
+    return dst, counts
+
+
+def radix_sort_builder(data) -> RadixSortBuilder:
+    """``RadixSort::radix_sort_builder`` (src/radix_sort.rs:29-31 / :42-44)."""
+    n_levels = key_info(data.dtype if _is_torch_tensor(data) else data.dtype.name)[2]
+    assert n_levels != 0, "RadixKey must have at least 1 level"  # radix_sort_builder.rs:22
+    return RadixSortBuilder(data)
+
+
+def radix_sort_unstable(data) -> None:
+    """``RadixSort::radix_sort_unstable`` (src/radix_sort.rs:25-27 / :38-40)."""
+    radix_sort_builder(data).sort()
+
+
+def set_tuning(chains=0, pass_config=0, hist_blocks_per_cu=0):
+    _lib.check(_lib.load().rdst_hip_set_tuning(int(chains), int(pass_config), int(hist_blocks_per_cu)))
