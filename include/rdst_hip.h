@@ -147,9 +147,9 @@ int rdst_pick_algorithm(int tuner_id, const rdst_tuning_params* p, const uint64_
 /* Bytes of device memory the workspace needs for a sort of `len` elements. */
 uint64_t rdst_hip_workspace_bytes(uint64_t len, uint32_t elem_bytes);
 
-/* Runtime knobs for experiments (kernel shape, number of look-back chains).  Values
- * <= 0 restore the built-in choice.  Not part of the reference surface. */
-int rdst_hip_set_tuning(int chains, int pass_config, int hist_blocks_per_cu);
+/* Runtime knobs for experiments (scatter-kernel shape, histogram grid).  Values <= 0
+ * restore the built-in choice.  Not part of the reference surface. */
+int rdst_hip_set_tuning(int pass_config, int hist_blocks_per_cu);
 
 /* Last error message of the calling thread ("" if none). */
 const char* rdst_hip_last_error(void);

@@ -77,7 +77,7 @@ def load():
     lib.rdst_pick_algorithm.argtypes = [ci, ctypes.POINTER(TuningParamsC), u64p, u64]
     lib.rdst_hip_workspace_bytes.argtypes = [u64, u32]
     lib.rdst_hip_workspace_bytes.restype = u64
-    lib.rdst_hip_set_tuning.argtypes = [ci, ci, ci]
+    lib.rdst_hip_set_tuning.argtypes = [ci, ci]
     lib.rdst_hip_last_error.restype = ctypes.c_char_p
     for name in SYMBOLS:
         if name not in ("rdst_hip_workspace_bytes", "rdst_hip_last_error"):

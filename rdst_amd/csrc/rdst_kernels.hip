@@ -4,12 +4,11 @@
 // (paths relative to the reference tree):
 //
 //   K1 hist_kernel        one coalesced read of the key slice -> 256-bin histograms of EVERY
-//                         level, per look-back chain.            get_counts_with_ends
+//                         level.                                 get_counts_with_ends
 //                         (src/sort_utils.rs:109-180), get_tile_counts (:193-244)
-//   K2 scan_kernel        256-bin exclusive scan per level + the (chain, digit) offset table
-//                         + the level-skip plan.                 get_prefix_sums (:10-20),
-//                         the (bucket, tile) carve of mt_lsb_sort (src/sorts/mt_lsb_sort.rs:51-54),
-//                         level skipping of lsb_sort_adapter (src/sorts/lsb_sort.rs:62-83)
+//   K2 scan_kernel        256-bin exclusive scan per level + the level-skip plan.
+//                         get_prefix_sums (:10-20), level skipping of lsb_sort_adapter
+//                         (src/sorts/lsb_sort.rs:62-83)
 //   K3 onesweep_kernel    one stable counting-sort pass: wave-ballot ranking, tile prefix by
 //                         chained scan with decoupled look-back. out_of_place_sort
 //                         (src/sorts/out_of_place_sort.rs:52-108), mt_lsb_sort (:40-133)
@@ -19,9 +18,11 @@
 // Data layout in HBM: keys are a dense array of K (u32 / u64 bit patterns; signed and float
 // keys stay in their raw encoding in memory, the order-preserving map is applied in registers
 // for digit extraction only).  `keys` and `tmp` ping-pong per executed pass.  The workspace
-// holds, per sort: an error word, per-(level, chain) tile tickets, the plan, per-chain
-// histograms u32[C][L][256], look-back status words u32[L][tiles][256], and the offset table
-// u64[L][C][256].
+// holds, per sort: an error word, per-level tile tickets, the plan, histograms u64[L][256],
+// look-back status words (u32 when n < 2^30, else u64) [L][tiles][256], and the bucket start
+// table u64[L][256].  A per-range ("multi-chain") offset table is NOT possible with one
+// up-front histogram: range histograms change with every pass's permutation, only the global
+// ones are permutation-invariant.
 //
 // Written for wave64 / 256 CUs in 8 XCDs only; no other target is supported.
 
@@ -40,15 +41,18 @@ namespace {
 
 constexpr int RADIX = 256;
 constexpr int MAX_LEVELS = 16;
-constexpr int MAX_CHAINS = 64;
 
-// look-back status word: [31:30] state, [29:0] value
+// look-back status word: top two bits state, the rest value (u32 for n < 2^30, u64 above)
 constexpr uint32_t ST_EMPTY = 0, ST_AGG = 1, ST_INCL = 2;
-constexpr uint32_t ST_VALUE_MASK = (1u << 30) - 1;
+template <typename S> struct StatusWord {
+    static constexpr int SHIFT = sizeof(S) * 8 - 2;
+    static constexpr S MASK = (S(1) << SHIFT) - 1;
+};
 // bounded spins: s_sleep(2) is ~128 clocks; 1<<22 polls is seconds, never reached in a healthy run
 constexpr uint32_t SPIN_LIMIT = 1u << 22;
 
 constexpr uint32_t ERR_LOOKBACK_TIMEOUT = 1;
+constexpr uint32_t ERR_SCATTER_RANGE = 2;  // a computed destination fell outside [0, n): never stored
 
 struct Plan {
     uint32_t skip[MAX_LEVELS];        // pass would move nothing (one bin holds every key)
@@ -77,10 +81,12 @@ __device__ __forceinline__ uint32_t digit_of(K mapped, int shift) {
     return (uint32_t)(mapped >> shift) & 0xFFu;
 }
 
-__device__ __forceinline__ uint32_t ld_relaxed(const uint32_t* p) {
+template <typename S>
+__device__ __forceinline__ S ld_relaxed(const S* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void st_relaxed(uint32_t* p, uint32_t v) {
+template <typename S>
+__device__ __forceinline__ void st_relaxed(S* p, S v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -100,80 +106,69 @@ __device__ __forceinline__ uint32_t lanes_below(uint64_t mask) {  // popcount(ma
 }
 
 // ------------------------------------------------------------------------------------------
-// K1: every level's histogram from one read.  grid = C * blocks_per_chain, block = 256.
+// K1: every level's histogram from one read.  block = 256, grid-contiguous pieces.
 // Per-wave 256-bin histograms in LDS (one copy per wave and level), block reduce, one global
 // atomic per non-empty (level, digit).  VEC = keys per 16-byte load (1 = unaligned fallback).
 // ------------------------------------------------------------------------------------------
 template <typename K, int LEVELS, int VEC>
-__global__ __launch_bounds__(256) void hist_kernel(const K* __restrict__ keys, uint64_t n,
-                                                   uint64_t chain_len, uint32_t blocks_per_chain,
-                                                   K neg, K pos, uint32_t* __restrict__ hist) {
+__global__ __launch_bounds__(256) void hist_kernel(const K* __restrict__ keys, uint64_t n, K neg, K pos,
+                                                   unsigned long long* __restrict__ hist) {
     __shared__ uint32_t s_h[4][LEVELS][RADIX];
     const int tid = threadIdx.x, wave = tid >> 6;
     for (int i = tid; i < 4 * LEVELS * RADIX; i += 256) (&s_h[0][0][0])[i] = 0;
     __syncthreads();
 
-    const uint32_t chain = blockIdx.x / blocks_per_chain;
-    const uint32_t bic = blockIdx.x % blocks_per_chain;
-    const uint64_t c_begin = (uint64_t)chain * chain_len;
-    const uint64_t c_end = (c_begin + chain_len < n) ? c_begin + chain_len : n;
-    if (c_begin < c_end) {
-        const uint64_t c_cnt = c_end - c_begin;
-        constexpr uint64_t GRAN = 256ull * VEC * 4;  // one unrolled sweep of the block
-        uint64_t piece = (c_cnt + blocks_per_chain - 1) / blocks_per_chain;
-        piece = (piece + GRAN - 1) / GRAN * GRAN;
-        const uint64_t p_begin = c_begin + (uint64_t)bic * piece;
-        uint64_t p_end = p_begin + piece;
-        if (p_end > c_end) p_end = c_end;
-        uint32_t(*wh)[RADIX] = s_h[wave];
+    constexpr uint64_t GRAN = 256ull * VEC * 4;  // one unrolled sweep of the block
+    uint64_t piece = (n + gridDim.x - 1) / gridDim.x;
+    piece = (piece + GRAN - 1) / GRAN * GRAN;
+    const uint64_t p_begin = (uint64_t)blockIdx.x * piece;
+    uint64_t p_end = p_begin + piece;
+    if (p_end > n) p_end = n;
+    uint32_t(*wh)[RADIX] = s_h[wave];
 
-        struct alignas(sizeof(K) * VEC) V { K e[VEC]; };
-        uint64_t i = p_begin + (uint64_t)tid * VEC;
-        constexpr uint64_t STRIDE = 256ull * VEC;
-        // full sweeps: 4 independent 16-byte loads in flight per lane
-        for (; p_begin < p_end && i + 3 * STRIDE + VEC <= p_end; i += 4 * STRIDE) {
-            V v[4];
+    struct alignas(sizeof(K) * VEC) V { K e[VEC]; };
+    uint64_t i = p_begin + (uint64_t)tid * VEC;
+    constexpr uint64_t STRIDE = 256ull * VEC;
+    // full sweeps: 4 independent 16-byte loads in flight per lane
+    for (; i + 3 * STRIDE + VEC <= p_end; i += 4 * STRIDE) {
+        V v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const V*>(keys + i + u * STRIDE);
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const V*>(keys + i + u * STRIDE);
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) {
-                    const K m = map_key<K>(v[u].e[e], neg, pos);
-#pragma unroll
-                    for (int l = 0; l < LEVELS; ++l) atomicAdd(&wh[l][digit_of(m, l * 8)], 1u);
-                }
-        }
-        // remainder of the piece, element-wise
-        for (; i < p_end; i += STRIDE) {
+        for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
-                if (i + e < p_end) {
-                    const K m = map_key<K>(keys[i + e], neg, pos);
+                const K m = map_key<K>(v[u].e[e], neg, pos);
 #pragma unroll
-                    for (int l = 0; l < LEVELS; ++l) atomicAdd(&wh[l][digit_of(m, l * 8)], 1u);
-                }
+                for (int l = 0; l < LEVELS; ++l) atomicAdd(&wh[l][digit_of(m, l * 8)], 1u);
+            }
+    }
+    // remainder of the piece, element-wise
+    for (; i < p_end; i += STRIDE) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            if (i + e < p_end) {
+                const K m = map_key<K>(keys[i + e], neg, pos);
+#pragma unroll
+                for (int l = 0; l < LEVELS; ++l) atomicAdd(&wh[l][digit_of(m, l * 8)], 1u);
             }
         }
     }
     __syncthreads();
-    uint32_t* out = hist + (size_t)chain * LEVELS * RADIX;
-    for (int i = tid; i < LEVELS * RADIX; i += 256) {
-        const int l = i >> 8, d = i & 255;
-        const uint32_t s = s_h[0][l][d] + s_h[1][l][d] + s_h[2][l][d] + s_h[3][l][d];
-        if (s) atomicAdd(&out[i], s);
+    for (int j = tid; j < LEVELS * RADIX; j += 256) {
+        const int l = j >> 8, d = j & 255;
+        const uint32_t c = s_h[0][l][d] + s_h[1][l][d] + s_h[2][l][d] + s_h[3][l][d];
+        if (c) atomicAdd(&hist[j], (unsigned long long)c);
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// K2: one block of 256 threads.  For every level: total per digit over chains, exclusive scan
-// over digits (u64), offset table base[level][chain][digit], and the skip plan.
+// K2: one block of 256 threads.  For every level: exclusive scan over the 256 digit totals
+// (u64) -> bucket start table, and the skip plan.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void scan_kernel(const uint32_t* __restrict__ hist,
-                                                   uint64_t* __restrict__ base, Plan* plan,
-                                                   uint64_t* __restrict__ totals_out,
-                                                   uint32_t C, uint32_t levels, uint64_t n,
-                                                   uint32_t allow_skip, uint32_t level_lo,
+__global__ __launch_bounds__(256) void scan_kernel(const unsigned long long* __restrict__ hist,
+                                                   uint64_t* __restrict__ base, Plan* plan, uint32_t levels,
+                                                   uint64_t n, uint32_t allow_skip, uint32_t level_lo,
                                                    uint32_t level_hi) {
     __shared__ uint64_t s_scan[RADIX];
     __shared__ uint32_t s_trivial[MAX_LEVELS];
@@ -181,9 +176,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint32_t* __restrict__ 
     if (d < MAX_LEVELS) s_trivial[d] = 0;
     __syncthreads();
     for (uint32_t l = 0; l < levels; ++l) {
-        uint64_t total = 0;
-        for (uint32_t c = 0; c < C; ++c) total += hist[((size_t)c * levels + l) * RADIX + d];
-        if (totals_out) totals_out[(size_t)l * RADIX + d] = total;
+        const uint64_t total = hist[(size_t)l * RADIX + d];
         if (total == n) s_trivial[l] = 1;
         // Hillis-Steele inclusive scan over 256 u64 values
         s_scan[d] = total;
@@ -194,11 +187,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint32_t* __restrict__ 
             s_scan[d] += y;
             __syncthreads();
         }
-        uint64_t run = s_scan[d] - total;
-        for (uint32_t c = 0; c < C; ++c) {
-            base[((size_t)l * C + c) * RADIX + d] = run;
-            run += hist[((size_t)c * levels + l) * RADIX + d];
-        }
+        base[(size_t)l * RADIX + d] = s_scan[d] - total;
         __syncthreads();
     }
     if (d == 0) {
@@ -216,23 +205,24 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint32_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
-// K3: one stable scatter pass.  grid = C * tiles_per_chain, block = NWAVES*64, one tile of
-// NWAVES*64*KPT keys per block, tile ids handed out by a per-chain ticket so that a tile's
-// predecessors have always started (forward progress of the look-back does not depend on
-// dispatch order).  blockIdx % C picks the chain: under the observed round-robin dispatch over
-// the 8 XCDs a chain's tiles then share one XCD (and its L2) when C == 8 — a speed property
-// only; every cross-workgroup word is an agent-scope relaxed atomic and the value carries its
-// own state bits, so no placement is assumed for correctness.
+// K3: one stable scatter pass.  grid = number of tiles, block = NWAVES*64, one tile of
+// NWAVES*64*KPT keys per block.  Tile ids come from a ticket counter so that a tile's
+// predecessors have always started: forward progress of the look-back does not depend on the
+// order in which the hardware dispatches workgroups, nor on where (which XCD) they land.
+// Every cross-workgroup word is an agent-scope relaxed atomic whose value carries its own state
+// bits (no separate flag, hence no fence).  S = status word type: u32 while every prefix fits
+// 30 bits (n < 2^30), u64 above.
 // ------------------------------------------------------------------------------------------
-template <typename K, int KPT, int NWAVES>
+template <typename K, typename S, int KPT, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64) void onesweep_kernel(
-    K* __restrict__ buf_keys, K* __restrict__ buf_tmp, uint64_t n, int level, uint32_t C,
-    uint32_t tiles_per_chain, const uint64_t* __restrict__ base /* [C][256] of this level */,
-    uint32_t* __restrict__ status /* [C*tiles_per_chain][256] of this level */,
-    uint32_t* __restrict__ tickets /* [C] of this level */, const Plan* __restrict__ plan,
-    uint32_t* __restrict__ err, K neg, K pos) {
+    K* __restrict__ buf_keys, K* __restrict__ buf_tmp, uint64_t n, int level,
+    const uint64_t* __restrict__ base /* [256] of this level */, S* __restrict__ status /* [tiles][256] of this level */,
+    uint32_t* __restrict__ ticket /* of this level */, const Plan* __restrict__ plan, uint32_t* __restrict__ err,
+    K neg, K pos) {
     constexpr int BLOCK = NWAVES * 64;
     constexpr int TILE = BLOCK * KPT;
+    constexpr int SSHIFT = StatusWord<S>::SHIFT;
+    constexpr S SMASK = StatusWord<S>::MASK;
     static_assert(BLOCK >= RADIX, "need one thread per digit");
 
     if (plan->skip[level]) return;
@@ -248,22 +238,17 @@ __global__ __launch_bounds__(NWAVES * 64) void onesweep_kernel(
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int shift = level * 8;
-    const uint32_t chain = blockIdx.x % C;
 
     if (tid == 0) {
-        s_misc[0] = atomicAdd(&tickets[chain], 1u);
+        s_misc[0] = atomicAdd(ticket, 1u);
         s_misc[1] = 0;  // block-wide failure flag
     }
     __syncthreads();
     const uint32_t t = s_misc[0];
-    const uint64_t chain_len = (uint64_t)tiles_per_chain * TILE;
-    const uint64_t c_begin = (uint64_t)chain * chain_len;
-    if (c_begin >= n) return;
-    const uint64_t c_end = (c_begin + chain_len < n) ? c_begin + chain_len : n;
-    const uint64_t tile_begin = c_begin + (uint64_t)t * TILE;
-    if (tile_begin >= c_end) return;
-    const uint32_t valid = (c_end - tile_begin < (uint64_t)TILE) ? (uint32_t)(c_end - tile_begin) : (uint32_t)TILE;
-    uint32_t* row = status + ((size_t)chain * tiles_per_chain + t) * RADIX;
+    const uint64_t tile_begin = (uint64_t)t * TILE;
+    if (tile_begin >= n) return;
+    const uint32_t valid = (n - tile_begin < (uint64_t)TILE) ? (uint32_t)(n - tile_begin) : (uint32_t)TILE;
+    S* row = status + (size_t)t * RADIX;
 
     // 1. load, wave-striped: lane l of wave w takes keys w*64*KPT + i*64 + l (256 contiguous
     //    bytes per wave-instruction for 4-byte keys), so index order == (wave, i, lane) order.
@@ -306,7 +291,7 @@ __global__ __launch_bounds__(NWAVES * 64) void onesweep_kernel(
         }
         pub = count_d;
         if (tid == RADIX - 1) pub -= (uint32_t)TILE - valid;  // sentinels are not keys
-        st_relaxed(&row[tid], ((t == 0 ? ST_INCL : ST_AGG) << 30) | pub);
+        st_relaxed<S>(&row[tid], ((S)(t == 0 ? ST_INCL : ST_AGG) << SSHIFT) | (S)pub);
     }
 
     // 4. exclusive scan of the 256 digit counts -> start of each digit's run inside the tile
@@ -351,36 +336,36 @@ __global__ __launch_bounds__(NWAVES * 64) void onesweep_kernel(
 #pragma unroll
     for (int i = 0; i < KPT; ++i) s_keys[posn[i]] = mk[i];
 
-    // 7. decoupled look-back over this chain's earlier tiles (thread d walks digit d)
+    // 7. decoupled look-back over the earlier tiles (thread d walks digit d)
     if (tid < RADIX) {
-        uint32_t excl = 0;
+        uint64_t excl = 0;
         bool fail = false;
         if (t > 0) {
-            const uint32_t* p = row - RADIX + tid;
+            const S* p = row - RADIX + tid;
             uint32_t spins = 0;
             for (;;) {
-                const uint32_t v = ld_relaxed(p);
-                const uint32_t st = v >> 30;
+                const S v = ld_relaxed<S>(p);
+                const uint32_t st = (uint32_t)(v >> SSHIFT);
                 if (st == ST_EMPTY) {
                     __builtin_amdgcn_s_sleep(2);
                     ++spins;
-                    if (spins > SPIN_LIMIT || ((spins & 1023u) == 0 && ld_relaxed(err) != 0)) {
+                    if (spins > SPIN_LIMIT || ((spins & 1023u) == 0 && ld_relaxed<uint32_t>(err) != 0)) {
                         fail = true;
                         break;
                     }
                     continue;
                 }
-                excl += v & ST_VALUE_MASK;
+                excl += (uint64_t)(v & SMASK);
                 if (st == ST_INCL) break;
-                p -= RADIX;  // tile 0 of a chain is always INCL, so this stays inside the chain
+                p -= RADIX;  // tile 0 is always INCL, so the walk stays inside the array
             }
-            if (!fail) st_relaxed(&row[tid], (ST_INCL << 30) | ((excl + pub) & ST_VALUE_MASK));
+            if (!fail) st_relaxed<S>(&row[tid], ((S)ST_INCL << SSHIFT) | ((S)(excl + pub) & SMASK));
         }
         if (fail) {
             atomicOr(err, ERR_LOOKBACK_TIMEOUT);
             s_misc[1] = 1;
         }
-        s_delta[tid] = base[(size_t)chain * RADIX + tid] + (uint64_t)excl - (uint64_t)local_off;
+        s_delta[tid] = base[tid] + excl - (uint64_t)local_off;
     }
     __syncthreads();
     if (s_misc[1]) return;  // never store with an unknown prefix
@@ -391,7 +376,11 @@ __global__ __launch_bounds__(NWAVES * 64) void onesweep_kernel(
         const uint32_t p = (uint32_t)tid + (uint32_t)i * BLOCK;
         const K k = s_keys[p];
         const uint32_t d = digit_of(k, shift);
-        if (p < valid) dst[s_delta[d] + p] = unmap_key<K>(k, neg, pos);
+        if (p < valid) {
+            const uint64_t g = s_delta[d] + p;
+            if (g < n) dst[g] = unmap_key<K>(k, neg, pos);
+            else atomicOr(err, ERR_SCATTER_RANGE);  // cannot happen with consistent counts; keeps a logic error from faulting
+        }
     }
 }
 
@@ -465,7 +454,7 @@ constexpr PassCfg kPassCfgs[] = {
 };
 constexpr int kNumPassCfgs = sizeof(kPassCfgs) / sizeof(kPassCfgs[0]);
 
-struct Tuning { int chains = 0; int pass_cfg = 0; int hist_bpc = 0; };
+struct Tuning { int pass_cfg = 0; int hist_bpc = 0; };
 Tuning g_tuning;
 std::mutex g_mutex;
 
@@ -482,9 +471,9 @@ struct DeviceState {
 DeviceState g_dev[16];
 
 struct Layout {
-    uint32_t C, tiles_per_chain, levels, tile;
-    uint64_t chain_len;
-    size_t off_err, off_tickets, off_plan, off_hist, off_status, zero_bytes, off_base, off_totals, total;
+    uint32_t levels, tile, status_bytes;  // status_bytes: 4 or 8 per word
+    uint64_t tiles;
+    size_t off_err, off_tickets, off_plan, off_hist, off_status, zero_bytes, off_base, total;
 };
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -494,32 +483,21 @@ int tile_keys(int cfg, uint32_t elem_bytes) {
     return p.nwaves * 64 * (elem_bytes == 8 ? p.kpt8 : p.kpt4);
 }
 
-Layout make_layout(uint64_t n, uint32_t elem_bytes, uint32_t levels, int cfg, int chains_pref) {
+Layout make_layout(uint64_t n, uint32_t elem_bytes, uint32_t levels, int cfg) {
     Layout L{};
     L.levels = levels;
     L.tile = (uint32_t)tile_keys(cfg, elem_bytes);
-    const uint64_t total_tiles = (n + L.tile - 1) / L.tile;
-    // a chain's inclusive prefix must fit 30 bits
-    const uint64_t max_chain_tiles = ((1ull << 30) - 1) / L.tile;
-    uint64_t C = chains_pref > 0 ? (uint64_t)chains_pref : 8;
-    if (total_tiles < 64 * C) C = 1;  // small inputs: one chain
-    uint64_t need = (total_tiles + max_chain_tiles - 1) / max_chain_tiles;
-    if (C < need) C = need;
-    if (C > MAX_CHAINS) C = MAX_CHAINS;
-    if (C < 1) C = 1;
-    L.C = (uint32_t)C;
-    L.tiles_per_chain = (uint32_t)((total_tiles + C - 1) / C);
-    if (L.tiles_per_chain == 0) L.tiles_per_chain = 1;
-    L.chain_len = (uint64_t)L.tiles_per_chain * L.tile;
+    L.tiles = (n + L.tile - 1) / L.tile;
+    if (L.tiles == 0) L.tiles = 1;
+    L.status_bytes = n < (1ull << 30) ? 4 : 8;  // an inclusive prefix can reach n
     size_t o = 0;
     L.off_err = o; o += 16;
-    L.off_tickets = o; o += sizeof(uint32_t) * MAX_LEVELS * MAX_CHAINS;
+    L.off_tickets = o; o += sizeof(uint32_t) * MAX_LEVELS;
     L.off_plan = o; o += align_up(sizeof(Plan), 16);
-    L.off_hist = o; o += sizeof(uint32_t) * (size_t)L.C * levels * RADIX;
-    L.off_status = o; o += sizeof(uint32_t) * (size_t)levels * L.C * L.tiles_per_chain * RADIX;
+    L.off_hist = o; o += sizeof(uint64_t) * (size_t)levels * RADIX;
+    L.off_status = o; o += (size_t)L.status_bytes * levels * L.tiles * RADIX;
     L.zero_bytes = align_up(o, 16); o = L.zero_bytes;
-    L.off_base = o; o += sizeof(uint64_t) * (size_t)levels * L.C * RADIX;
-    L.off_totals = o; o += sizeof(uint64_t) * (size_t)levels * RADIX;
+    L.off_base = o; o += sizeof(uint64_t) * (size_t)levels * RADIX;
     L.total = align_up(o, 256);
     return L;
 }
@@ -586,63 +564,69 @@ KeyMap key_map_for(rdst_key_kind kind, uint32_t elem_bytes) {
 }
 
 template <typename K, int LEVELS>
-int launch_hist(const K* keys, uint64_t n, const Layout& L, uint32_t bpc, KeyMap km, uint32_t* hist, hipStream_t s) {
-    const dim3 grid(L.C * bpc), block(256);
+int launch_hist(const K* keys, uint64_t n, uint32_t blocks, KeyMap km, unsigned long long* hist, hipStream_t s) {
+    const dim3 grid(blocks), block(256);
     const bool aligned = (reinterpret_cast<uintptr_t>(keys) & 15u) == 0;
     constexpr int VEC = 16 / sizeof(K);
     if (aligned)
-        hipLaunchKernelGGL((hist_kernel<K, LEVELS, VEC>), grid, block, 0, s, keys, n, L.chain_len, bpc, (K)km.neg, (K)km.pos, hist);
+        hipLaunchKernelGGL((hist_kernel<K, LEVELS, VEC>), grid, block, 0, s, keys, n, (K)km.neg, (K)km.pos, hist);
     else
-        hipLaunchKernelGGL((hist_kernel<K, LEVELS, 1>), grid, block, 0, s, keys, n, L.chain_len, bpc, (K)km.neg, (K)km.pos, hist);
+        hipLaunchKernelGGL((hist_kernel<K, LEVELS, 1>), grid, block, 0, s, keys, n, (K)km.neg, (K)km.pos, hist);
     HIP_TRY(hipGetLastError());
     return RDST_OK;
 }
 
-template <typename K, int KPT, int NWAVES>
+template <typename K, typename S, int KPT, int NWAVES>
 int launch_pass_t(K* keys, K* tmp, uint64_t n, int level, const Layout& L, char* ws, KeyMap km, hipStream_t s) {
     constexpr int TILE = NWAVES * 64 * KPT;
     const size_t lds = (size_t)NWAVES * 1024 + 2048 + 64 + sizeof(K) * TILE;
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&onesweep_kernel<K, KPT, NWAVES>),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&onesweep_kernel<K, S, KPT, NWAVES>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    const uint64_t* base = reinterpret_cast<const uint64_t*>(ws + L.off_base) + (size_t)level * L.C * RADIX;
-    uint32_t* status = reinterpret_cast<uint32_t*>(ws + L.off_status) + (size_t)level * L.C * L.tiles_per_chain * RADIX;
-    uint32_t* tickets = reinterpret_cast<uint32_t*>(ws + L.off_tickets) + (size_t)level * MAX_CHAINS;
+    const uint64_t* base = reinterpret_cast<const uint64_t*>(ws + L.off_base) + (size_t)level * RADIX;
+    S* status = reinterpret_cast<S*>(ws + L.off_status) + (size_t)level * L.tiles * RADIX;
+    uint32_t* ticket = reinterpret_cast<uint32_t*>(ws + L.off_tickets) + level;
     const Plan* plan = reinterpret_cast<const Plan*>(ws + L.off_plan);
     uint32_t* err = reinterpret_cast<uint32_t*>(ws + L.off_err);
-    const dim3 grid(L.C * L.tiles_per_chain), block(NWAVES * 64);
-    hipLaunchKernelGGL((onesweep_kernel<K, KPT, NWAVES>), grid, block, lds, s, keys, tmp, n, level, L.C,
-                       L.tiles_per_chain, base, status, tickets, plan, err, (K)km.neg, (K)km.pos);
+    const dim3 grid((uint32_t)L.tiles), block(NWAVES * 64);
+    hipLaunchKernelGGL((onesweep_kernel<K, S, KPT, NWAVES>), grid, block, lds, s, keys, tmp, n, level, base, status,
+                       ticket, plan, err, (K)km.neg, (K)km.pos);
     HIP_TRY(hipGetLastError());
     return RDST_OK;
 }
 
-template <typename K>
-int launch_pass(int cfg, K* keys, K* tmp, uint64_t n, int level, const Layout& L, char* ws, KeyMap km, hipStream_t s) {
+template <typename K, typename S>
+int launch_pass_s(int cfg, K* keys, K* tmp, uint64_t n, int level, const Layout& L, char* ws, KeyMap km, hipStream_t s) {
     if constexpr (sizeof(K) == 4) {
         switch (cfg) {
-            case 0: return launch_pass_t<K, 16, 8>(keys, tmp, n, level, L, ws, km, s);
-            case 1: return launch_pass_t<K, 16, 16>(keys, tmp, n, level, L, ws, km, s);
-            case 2: return launch_pass_t<K, 16, 4>(keys, tmp, n, level, L, ws, km, s);
-            case 3: return launch_pass_t<K, 24, 8>(keys, tmp, n, level, L, ws, km, s);
+            case 0: return launch_pass_t<K, S, 16, 8>(keys, tmp, n, level, L, ws, km, s);
+            case 1: return launch_pass_t<K, S, 16, 16>(keys, tmp, n, level, L, ws, km, s);
+            case 2: return launch_pass_t<K, S, 16, 4>(keys, tmp, n, level, L, ws, km, s);
+            case 3: return launch_pass_t<K, S, 24, 8>(keys, tmp, n, level, L, ws, km, s);
         }
     } else {
         switch (cfg) {
-            case 0: return launch_pass_t<K, 8, 8>(keys, tmp, n, level, L, ws, km, s);
-            case 1: return launch_pass_t<K, 8, 16>(keys, tmp, n, level, L, ws, km, s);
-            case 2: return launch_pass_t<K, 8, 4>(keys, tmp, n, level, L, ws, km, s);
-            case 3: return launch_pass_t<K, 12, 8>(keys, tmp, n, level, L, ws, km, s);
+            case 0: return launch_pass_t<K, S, 8, 8>(keys, tmp, n, level, L, ws, km, s);
+            case 1: return launch_pass_t<K, S, 8, 16>(keys, tmp, n, level, L, ws, km, s);
+            case 2: return launch_pass_t<K, S, 8, 4>(keys, tmp, n, level, L, ws, km, s);
+            case 3: return launch_pass_t<K, S, 12, 8>(keys, tmp, n, level, L, ws, km, s);
         }
     }
     return fail(RDST_ERR_ARG, "bad pass config");
 }
 
+template <typename K>
+int launch_pass(int cfg, K* keys, K* tmp, uint64_t n, int level, const Layout& L, char* ws, KeyMap km, hipStream_t s) {
+    if (L.status_bytes == 4) return launch_pass_s<K, uint32_t>(cfg, keys, tmp, n, level, L, ws, km, s);
+    return launch_pass_s<K, unsigned long long>(cfg, keys, tmp, n, level, L, ws, km, s);
+}
+
 // The whole device-side pipeline for levels [level_lo, level_hi): memset, K1, K2, passes,
 // optional copy-back.  `allow_skip` turns on level skipping.  With copy_back == false the
-// caller reads Plan::result_in_tmp itself (scatter hook).
+// result stays where the last executed pass put it (scatter hook: exactly one pass keys->tmp).
 template <typename K, int LEVELS>
 int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level_lo, uint32_t level_hi,
                  bool allow_skip, bool copy_back, hipStream_t s, Layout* layout_out, char** ws_out) {
@@ -651,7 +635,8 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     if (rc) return rc;
     int cfg = g_tuning.pass_cfg;
     if (cfg < 0 || cfg >= kNumPassCfgs) cfg = 0;
-    const Layout L = make_layout(n, sizeof(K), LEVELS, cfg, g_tuning.chains);
+    const Layout L = make_layout(n, sizeof(K), LEVELS, cfg);
+    if (L.tiles >= (1ull << 31)) return fail(RDST_ERR_ARG, "len too large for one launch");
     rc = ensure_workspace(*D, L.total);
     if (rc) return rc;
     char* ws = static_cast<char*>(D->ws);
@@ -659,20 +644,24 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     rc = workspace_acquire(*D, s);
     if (rc) return rc;
 
-    HIP_TRY(hipMemsetAsync(ws, 0, L.zero_bytes, s));
+    // only the status rows of the passes that can run need clearing
+    const size_t status_lo = L.off_status + (size_t)L.status_bytes * level_lo * L.tiles * RADIX;
+    const size_t status_hi = L.off_status + (size_t)L.status_bytes * level_hi * L.tiles * RADIX;
+    HIP_TRY(hipMemsetAsync(ws, 0, L.off_status, s));
+    if (status_hi > status_lo) HIP_TRY(hipMemsetAsync(ws + status_lo, 0, status_hi - status_lo, s));
+
     // K1: enough blocks to fill the chip several times over, but no more than the data needs
-    uint32_t bpc_pref = (uint32_t)((g_tuning.hist_bpc > 0 ? g_tuning.hist_bpc : 8) * D->cus);
-    uint32_t bpc = (bpc_pref + L.C - 1) / L.C;
+    uint64_t blocks = (uint64_t)(g_tuning.hist_bpc > 0 ? g_tuning.hist_bpc : 8) * D->cus;
     const uint64_t per_block_min = 256ull * (16 / sizeof(K)) * 4;
-    const uint64_t max_useful = (L.chain_len + per_block_min - 1) / per_block_min;
-    if (bpc > max_useful) bpc = (uint32_t)max_useful;
-    if (bpc < 1) bpc = 1;
-    uint32_t* hist = reinterpret_cast<uint32_t*>(ws + L.off_hist);
-    rc = launch_hist<K, LEVELS>(keys, n, L, bpc, km, hist, s);
+    const uint64_t max_useful = (n + per_block_min - 1) / per_block_min;
+    if (blocks > max_useful) blocks = max_useful;
+    if (blocks < 1) blocks = 1;
+    unsigned long long* hist = reinterpret_cast<unsigned long long*>(ws + L.off_hist);
+    rc = launch_hist<K, LEVELS>(keys, n, (uint32_t)blocks, km, hist, s);
     if (rc) return rc;
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(256), 0, s, hist, reinterpret_cast<uint64_t*>(ws + L.off_base),
-                       reinterpret_cast<Plan*>(ws + L.off_plan), reinterpret_cast<uint64_t*>(ws + L.off_totals),
-                       L.C, (uint32_t)LEVELS, n, allow_skip ? 1u : 0u, level_lo, level_hi);
+                       reinterpret_cast<Plan*>(ws + L.off_plan), (uint32_t)LEVELS, n, allow_skip ? 1u : 0u, level_lo,
+                       level_hi);
     HIP_TRY(hipGetLastError());
     for (uint32_t level = level_lo; level < level_hi; ++level) {
         rc = launch_pass<K>(cfg, keys, tmp, n, (int)level, L, ws, km, s);
@@ -680,16 +669,16 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     }
     if (copy_back) {
         const bool aligned = ((reinterpret_cast<uintptr_t>(keys) | reinterpret_cast<uintptr_t>(tmp)) & 15u) == 0;
-        uint64_t blocks = (n * sizeof(K) / 16 + 255) / 256;
+        uint64_t cblocks = (n * sizeof(K) / 16 + 255) / 256;
         const uint64_t cap = (uint64_t)D->cus * 16;
-        if (blocks > cap) blocks = cap;
-        if (blocks < 1) blocks = 1;
+        if (cblocks > cap) cblocks = cap;
+        if (cblocks < 1) cblocks = 1;
         const Plan* plan = reinterpret_cast<const Plan*>(ws + L.off_plan);
         constexpr int VEC = 16 / sizeof(K);
         if (aligned)
-            hipLaunchKernelGGL((copyback_kernel<K, VEC>), dim3((uint32_t)blocks), dim3(256), 0, s, keys, tmp, n, plan);
+            hipLaunchKernelGGL((copyback_kernel<K, VEC>), dim3((uint32_t)cblocks), dim3(256), 0, s, keys, tmp, n, plan);
         else
-            hipLaunchKernelGGL((copyback_kernel<K, 1>), dim3((uint32_t)blocks), dim3(256), 0, s, keys, tmp, n, plan);
+            hipLaunchKernelGGL((copyback_kernel<K, 1>), dim3((uint32_t)cblocks), dim3(256), 0, s, keys, tmp, n, plan);
         HIP_TRY(hipGetLastError());
     }
     if (layout_out) *layout_out = L;
@@ -714,7 +703,7 @@ int read_device_error(DeviceState& D, hipStream_t s) {
     HIP_TRY(hipStreamSynchronize(s));
     if (*D.host_err != 0) {
         char b[128];
-        snprintf(b, sizeof b, "device error word = 0x%x (look-back spin bound expired)", *D.host_err);
+        snprintf(b, sizeof b, "device error word = 0x%x (1 = look-back spin bound expired, 2 = scatter destination out of range)", *D.host_err);
         return fail(RDST_ERR_DEVICE, b);
     }
     return RDST_OK;
@@ -730,10 +719,9 @@ extern "C" {
 const char* rdst_hip_last_error(void) { return g_last_error.c_str(); }
 int rdst_hip_abi_version(void) { return RDST_HIP_ABI_VERSION; }
 
-int rdst_hip_set_tuning(int chains, int pass_config, int hist_blocks_per_cu) {
+int rdst_hip_set_tuning(int pass_config, int hist_blocks_per_cu) {
     std::lock_guard<std::mutex> lock(g_mutex);
-    if (chains > MAX_CHAINS || pass_config >= kNumPassCfgs) return fail(RDST_ERR_ARG, "tuning value out of range");
-    g_tuning.chains = chains > 0 ? chains : 0;
+    if (pass_config >= kNumPassCfgs) return fail(RDST_ERR_ARG, "tuning value out of range");
     g_tuning.pass_cfg = pass_config > 0 ? pass_config : 0;
     g_tuning.hist_bpc = hist_blocks_per_cu > 0 ? hist_blocks_per_cu : 0;
     return RDST_OK;
@@ -742,7 +730,7 @@ int rdst_hip_set_tuning(int chains, int pass_config, int hist_blocks_per_cu) {
 uint64_t rdst_hip_workspace_bytes(uint64_t len, uint32_t elem_bytes) {
     if (elem_bytes != 4 && elem_bytes != 8) return 0;
     int cfg = g_tuning.pass_cfg;
-    return make_layout(len, elem_bytes, elem_bytes, cfg, g_tuning.chains).total;
+    return make_layout(len, elem_bytes, elem_bytes, cfg).total;
 }
 
 int rdst_hip_sort_device(void* dev_keys, void* dev_tmp, uint64_t len, uint32_t elem_bytes, rdst_key_kind kind,
@@ -820,7 +808,7 @@ int rdst_hip_all_level_counts(const void* dev_keys, uint64_t len, uint32_t elem_
     else
         rc = run_pipeline<uint64_t, 8>(const_cast<uint64_t*>(static_cast<const uint64_t*>(dev_keys)), nullptr, len, kind, 0, 0, false, false, s, &L, &ws);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(counts_out, ws + L.off_totals, sizeof(uint64_t) * levels * RADIX, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(counts_out, ws + L.off_hist, sizeof(uint64_t) * levels * RADIX, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return RDST_OK;
 }
@@ -845,7 +833,7 @@ int rdst_hip_scatter_level(const void* dev_src, void* dev_dst, uint64_t len, uin
         rc = run_pipeline<uint64_t, 8>(const_cast<uint64_t*>(static_cast<const uint64_t*>(dev_src)), static_cast<uint64_t*>(dev_dst), len, kind, level, level + 1, false, false, s, &L, &ws);
     if (rc) return rc;
     if (counts_out)
-        HIP_TRY(hipMemcpyAsync(counts_out, ws + L.off_totals + sizeof(uint64_t) * (size_t)level * RADIX, sizeof(uint64_t) * RADIX, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(counts_out, ws + L.off_hist + sizeof(uint64_t) * (size_t)level * RADIX, sizeof(uint64_t) * RADIX, hipMemcpyDeviceToHost, s));
     DeviceState* D;
     rc = current_device_state(&D);
     if (rc) return rc;
