@@ -151,6 +151,17 @@ uint64_t rdst_hip_workspace_bytes(uint64_t len, uint32_t elem_bytes);
  * restore the built-in choice.  Not part of the reference surface. */
 int rdst_hip_set_tuning(int pass_config, int hist_blocks_per_cu);
 
+/* Per-kernel device timing for benchmarks.  While enabled, every pipeline (sort / hook call)
+ * records HIP events on its own stream between its launches and appends one "run" to a
+ * per-device list; enabling again clears the list.  rdst_hip_profile_run blocks until run
+ * `run` (negative = counted from the most recent) has finished and writes the elapsed
+ * milliseconds of its stages in launch order: [0] workspace clear, [1] multi-level histogram
+ * (K1), [2] scan (K2), then one entry per scatter pass (K3) for the levels the call covered,
+ * then the conditional copy-back if the call has one.  *n_out = entries written. */
+int rdst_hip_set_profiling(int enabled);
+int rdst_hip_profile_runs(void);
+int rdst_hip_profile_run(int run, float* out_ms, uint32_t capacity, uint32_t* n_out);
+
 /* Last error message of the calling thread ("" if none). */
 const char* rdst_hip_last_error(void);
 

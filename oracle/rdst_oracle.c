@@ -167,6 +167,7 @@ static int single_algo_tuner(void* ctx, const struct rdst_o_tuning_params* p, co
 /* ---- element types: RadixKey impls — src/radix_key_impl.rs -------------------------------- */
 typedef unsigned __int128 u128;
 typedef struct { uint8_t b[3]; } bytes3;
+typedef struct { uint8_t b[4]; } bytes4;
 
 /* unsigned: (self >> (level * 8)) as u8 — :3-76 */
 #define T uint8_t
@@ -204,6 +205,26 @@ typedef struct { uint8_t b[3]; } bytes3;
 #define SUF b3
 #define LEVELS 3
 #define GET_LEVEL(v, level) ((v).b[3 - (level)-1])
+#include "rdst_oracle_impl.h"
+
+/* The three user-defined keys of examples/impl_radix_key.rs:5-56 (known-answer vectors only):
+ * PackedU8 = lexicographic [u8; 4]; EvenSortedPackedU8 / OddSortedPackedU8 = 2-level partial keys. */
+#define T bytes4
+#define SUF b4
+#define LEVELS 4
+#define GET_LEVEL(v, level) ((v).b[3 - (level)])
+#include "rdst_oracle_impl.h"
+
+#define T bytes4
+#define SUF pk_even
+#define LEVELS 2
+#define GET_LEVEL(v, level) ((v).b[3 - (level)*2])
+#include "rdst_oracle_impl.h"
+
+#define T bytes4
+#define SUF pk_odd
+#define LEVELS 2
+#define GET_LEVEL(v, level) ((v).b[3 - ((level)*2 + 1)])
 #include "rdst_oracle_impl.h"
 
 /* signed: ((self ^ MIN) >> (level * 8)) as u8 — :87-160.  Elements are held as raw bit
@@ -266,8 +287,8 @@ static inline uint64_t f64_key(uint64_t bits) {
 
 /* ---- exported surface ---------------------------------------------------------------------- */
 
-static const size_t k_elem_bytes[RDST_O_NUM_TYPES] = {1, 2, 4, 8, 16, 1, 2, 4, 8, 16, 4, 8, 3};
-static const size_t k_levels[RDST_O_NUM_TYPES] = {1, 2, 4, 8, 16, 1, 2, 4, 8, 16, 4, 8, 3};
+static const size_t k_elem_bytes[RDST_O_NUM_TYPES] = {1, 2, 4, 8, 16, 1, 2, 4, 8, 16, 4, 8, 3, 4, 4, 4};
+static const size_t k_levels[RDST_O_NUM_TYPES] = {1, 2, 4, 8, 16, 1, 2, 4, 8, 16, 4, 8, 3, 4, 2, 2};
 
 size_t rdst_oracle_elem_bytes(int type_id) { return (type_id < 0 || type_id >= RDST_O_NUM_TYPES) ? 0 : k_elem_bytes[type_id]; }
 size_t rdst_oracle_levels(int type_id) { return (type_id < 0 || type_id >= RDST_O_NUM_TYPES) ? 0 : k_levels[type_id]; }
@@ -287,6 +308,9 @@ size_t rdst_oracle_levels(int type_id) { return (type_id < 0 || type_id >= RDST_
         case RDST_O_F32: { typedef uint32_t E; CALL(f32); } break;      \
         case RDST_O_F64: { typedef uint64_t E; CALL(f64); } break;      \
         case RDST_O_B3: { typedef bytes3 E; CALL(b3); } break;          \
+        case RDST_O_B4: { typedef bytes4 E; CALL(b4); } break;          \
+        case RDST_O_PK_EVEN: { typedef bytes4 E; CALL(pk_even); } break; \
+        case RDST_O_PK_ODD: { typedef bytes4 E; CALL(pk_odd); } break;  \
         default: return -1;                                             \
     }
 

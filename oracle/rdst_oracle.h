@@ -13,6 +13,7 @@ enum {
     RDST_O_U8 = 0, RDST_O_U16, RDST_O_U32, RDST_O_U64, RDST_O_U128,
     RDST_O_I8, RDST_O_I16, RDST_O_I32, RDST_O_I64, RDST_O_I128,
     RDST_O_F32, RDST_O_F64, RDST_O_B3,
+    RDST_O_B4, RDST_O_PK_EVEN, RDST_O_PK_ODD, /* examples/impl_radix_key.rs */
     RDST_O_NUM_TYPES
 };
 enum { RDST_O_TUNER_STANDARD = 0, RDST_O_TUNER_LOW_MEMORY = 1, RDST_O_TUNER_SINGLE_THREADED = 2 };

@@ -19,6 +19,10 @@ from .radix_sort import (  # noqa: F401
     radix_sort_unstable,
     scatter_level,
     set_tuning,
+    set_profiling,
+    last_profile,
+    profile_run,
+    profile_runs,
     sort_device_tensor,
     sort_host_array,
 )
@@ -27,5 +31,5 @@ from ._lib import RdstHipError  # noqa: F401
 __all__ = [
     "radix_sort_unstable", "radix_sort_builder", "RadixSortBuilder", "tuner", "RdstHipError",
     "sort_device_tensor", "sort_host_array", "level_counts", "all_level_counts", "scatter_level",
-    "device_status", "set_tuning", "key_info",
+    "device_status", "set_tuning", "set_profiling", "last_profile", "key_info",
 ]

@@ -24,6 +24,9 @@ SYMBOLS = (
     "rdst_pick_algorithm",
     "rdst_hip_workspace_bytes",
     "rdst_hip_set_tuning",
+    "rdst_hip_set_profiling",
+    "rdst_hip_profile_runs",
+    "rdst_hip_profile_run",
     "rdst_hip_last_error",
     "rdst_hip_abi_version",
 )
@@ -78,6 +81,8 @@ def load():
     lib.rdst_hip_workspace_bytes.argtypes = [u64, u32]
     lib.rdst_hip_workspace_bytes.restype = u64
     lib.rdst_hip_set_tuning.argtypes = [ci, ci]
+    lib.rdst_hip_set_profiling.argtypes = [ci]
+    lib.rdst_hip_profile_run.argtypes = [ci, ctypes.POINTER(ctypes.c_float), u32, ctypes.POINTER(u32)]
     lib.rdst_hip_last_error.restype = ctypes.c_char_p
     for name in SYMBOLS:
         if name not in ("rdst_hip_workspace_bytes", "rdst_hip_last_error"):

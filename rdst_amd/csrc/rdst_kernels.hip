@@ -454,7 +454,7 @@ constexpr PassCfg kPassCfgs[] = {
 };
 constexpr int kNumPassCfgs = sizeof(kPassCfgs) / sizeof(kPassCfgs[0]);
 
-struct Tuning { int pass_cfg = 0; int hist_bpc = 0; };
+struct Tuning { int pass_cfg = 0; int hist_bpc = 0; bool profiling = false; };
 Tuning g_tuning;
 std::mutex g_mutex;
 
@@ -467,6 +467,12 @@ struct DeviceState {
     hipEvent_t last_done = nullptr;  // recorded after every enqueue that uses the workspace
     hipStream_t last_stream = nullptr;
     bool have_last = false;
+    // per-kernel timing (rdst_hip_set_profiling): events recorded between the launches of the
+    // most recent pipeline, on the stream the kernels run on
+    std::vector<hipEvent_t> prof_events;
+    uint32_t prof_used = 0;
+    struct ProfRun { uint32_t begin, count; };
+    std::vector<ProfRun> prof_runs;  // one per pipeline since profiling was (re-)enabled
 };
 DeviceState g_dev[16];
 
@@ -550,6 +556,18 @@ int workspace_release(DeviceState& D, hipStream_t s) {
     HIP_TRY(hipEventRecord(D.last_done, s));
     D.last_stream = s;
     D.have_last = true;
+    return RDST_OK;
+}
+
+int prof_mark(DeviceState& D, hipStream_t s) {
+    if (!g_tuning.profiling || D.prof_runs.empty() || D.prof_used >= 8192) return RDST_OK;
+    if (D.prof_used == D.prof_events.size()) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        D.prof_events.push_back(e);
+    }
+    HIP_TRY(hipEventRecord(D.prof_events[D.prof_used++], s));
+    D.prof_runs.back().count = D.prof_used - D.prof_runs.back().begin;
     return RDST_OK;
 }
 
@@ -647,8 +665,11 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     // only the status rows of the passes that can run need clearing
     const size_t status_lo = L.off_status + (size_t)L.status_bytes * level_lo * L.tiles * RADIX;
     const size_t status_hi = L.off_status + (size_t)L.status_bytes * level_hi * L.tiles * RADIX;
+    if (g_tuning.profiling) D->prof_runs.push_back({D->prof_used, 0});
+    if ((rc = prof_mark(*D, s))) return rc;
     HIP_TRY(hipMemsetAsync(ws, 0, L.off_status, s));
     if (status_hi > status_lo) HIP_TRY(hipMemsetAsync(ws + status_lo, 0, status_hi - status_lo, s));
+    if ((rc = prof_mark(*D, s))) return rc;
 
     // K1: enough blocks to fill the chip several times over, but no more than the data needs
     uint64_t blocks = (uint64_t)(g_tuning.hist_bpc > 0 ? g_tuning.hist_bpc : 8) * D->cus;
@@ -659,13 +680,16 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     unsigned long long* hist = reinterpret_cast<unsigned long long*>(ws + L.off_hist);
     rc = launch_hist<K, LEVELS>(keys, n, (uint32_t)blocks, km, hist, s);
     if (rc) return rc;
+    if ((rc = prof_mark(*D, s))) return rc;
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(256), 0, s, hist, reinterpret_cast<uint64_t*>(ws + L.off_base),
                        reinterpret_cast<Plan*>(ws + L.off_plan), (uint32_t)LEVELS, n, allow_skip ? 1u : 0u, level_lo,
                        level_hi);
     HIP_TRY(hipGetLastError());
+    if ((rc = prof_mark(*D, s))) return rc;
     for (uint32_t level = level_lo; level < level_hi; ++level) {
         rc = launch_pass<K>(cfg, keys, tmp, n, (int)level, L, ws, km, s);
         if (rc) return rc;
+        if ((rc = prof_mark(*D, s))) return rc;
     }
     if (copy_back) {
         const bool aligned = ((reinterpret_cast<uintptr_t>(keys) | reinterpret_cast<uintptr_t>(tmp)) & 15u) == 0;
@@ -680,6 +704,7 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
         else
             hipLaunchKernelGGL((copyback_kernel<K, 1>), dim3((uint32_t)cblocks), dim3(256), 0, s, keys, tmp, n, plan);
         HIP_TRY(hipGetLastError());
+        if ((rc = prof_mark(*D, s))) return rc;
     }
     if (layout_out) *layout_out = L;
     if (ws_out) *ws_out = ws;
@@ -724,6 +749,42 @@ int rdst_hip_set_tuning(int pass_config, int hist_blocks_per_cu) {
     if (pass_config >= kNumPassCfgs) return fail(RDST_ERR_ARG, "tuning value out of range");
     g_tuning.pass_cfg = pass_config > 0 ? pass_config : 0;
     g_tuning.hist_bpc = hist_blocks_per_cu > 0 ? hist_blocks_per_cu : 0;
+    return RDST_OK;
+}
+
+int rdst_hip_set_profiling(int enabled) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    g_tuning.profiling = enabled != 0;
+    for (auto& D : g_dev) {  // (re-)enabling starts a fresh record list
+        D.prof_used = 0;
+        D.prof_runs.clear();
+    }
+    return RDST_OK;
+}
+
+int rdst_hip_profile_runs(void) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    DeviceState* D;
+    if (current_device_state(&D)) return 0;
+    return (int)D->prof_runs.size();
+}
+
+int rdst_hip_profile_run(int run, float* out_ms, uint32_t capacity, uint32_t* n_out) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    DeviceState* D;
+    int rc = current_device_state(&D);
+    if (rc) return rc;
+    if (!out_ms || !n_out) return fail(RDST_ERR_ARG, "null output");
+    *n_out = 0;
+    if (run < 0) run += (int)D->prof_runs.size();  // -1 = most recent
+    if (run < 0 || run >= (int)D->prof_runs.size()) return fail(RDST_ERR_ARG, "no such profiled run");
+    const auto r = D->prof_runs[run];
+    if (r.count < 2) return RDST_OK;
+    HIP_TRY(hipEventSynchronize(D->prof_events[r.begin + r.count - 1]));
+    const uint32_t n = r.count - 1;
+    for (uint32_t i = 0; i < n && i < capacity; ++i)
+        HIP_TRY(hipEventElapsedTime(&out_ms[i], D->prof_events[r.begin + i], D->prof_events[r.begin + i + 1]));
+    *n_out = n < capacity ? n : capacity;
     return RDST_OK;
 }
 

@@ -222,3 +222,31 @@ def radix_sort_unstable(data) -> None:
 
 def set_tuning(pass_config=0, hist_blocks_per_cu=0):
     _lib.check(_lib.load().rdst_hip_set_tuning(int(pass_config), int(hist_blocks_per_cu)))
+
+
+def set_profiling(enabled: bool):
+    """Record HIP events between the kernels of every following sort (rdst_hip_set_profiling)."""
+    _lib.check(_lib.load().rdst_hip_set_profiling(int(bool(enabled))))
+
+
+def profile_runs() -> int:
+    """Number of pipelines recorded since profiling was enabled (current device)."""
+    return int(_lib.load().rdst_hip_profile_runs())
+
+
+def profile_run(run: int, levels: int):
+    """Stage times (ms) of recorded run `run` (negative: from the most recent): dict with
+    'clear', 'histogram', 'scan', 'passes' (one per level) and 'copy_back'."""
+    lib = _lib.load()
+    buf = (ctypes.c_float * 32)()
+    n = ctypes.c_uint32(0)
+    _lib.check(lib.rdst_hip_profile_run(int(run), buf, 32, ctypes.byref(n)))
+    v = [float(buf[i]) for i in range(n.value)]
+    if len(v) < 3 + levels:
+        return None
+    return {"clear": v[0], "histogram": v[1], "scan": v[2], "passes": v[3:3 + levels],
+            "copy_back": v[3 + levels] if len(v) > 3 + levels else 0.0}
+
+
+def last_profile(levels: int):
+    return profile_run(-1, levels) if profile_runs() else None

@@ -1,0 +1,187 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the CPU oracle on the
+same seeded inputs (bit-exact: integer / byte work), against the committed golden vectors,
+and the edge cases the reference tests (empty, one element, tile boundaries, all-equal,
+sorted, reverse, masked bit patterns, bimodal shifts, float specials)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import (DTYPES, gen_inputs, mapped_key, random_bits, reference_sorted, same_bits, to_device, to_host,
+                     u32_patterns)
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _device_sort(rdst, a):
+    t = to_device(a)
+    rdst.radix_sort_unstable(t)
+    return to_host(t, a.dtype)
+
+
+def test_native_library_is_the_one_in_tree(gpu):
+    from rdst_amd import _lib
+    assert os.path.dirname(_lib.LIB_PATH) == os.path.join(os.path.dirname(HERE), "rdst_amd")
+    assert _lib.load().rdst_hip_abi_version() == 1
+    maps = open("/proc/self/maps").read()
+    assert "librdst_hip.so" in maps
+
+
+def test_golden_known_answers_on_device(gpu):
+    ka = json.load(open(os.path.join(HERE, "golden", "reference_known_answers.json")))
+    for case in ka["sorts"]:
+        if case["type"] == "uint32":
+            a = np.array(case["input"], dtype=np.uint32)
+            assert _device_sort(gpu, a).tolist() == case["expected"], case["source"]
+        elif case["type"] == "b4":  # [u8;4] lexicographic == big-endian u32
+            a = np.array(case["input"], dtype=np.uint8).view(">u4").astype(np.uint32).ravel()
+            got = _device_sort(gpu, a).astype(">u4").view(np.uint8).reshape(-1, 4)
+            assert got.tolist() == case["expected"], case["source"]
+
+
+def test_host_entry_point_sorts_numpy_in_place(gpu, oracle):
+    for dtype in DTYPES:
+        a = random_bits(300_001, dtype, seed=5).copy()
+        exp = a.copy()
+        oracle.sort(exp, threads=4)
+        gpu.radix_sort_unstable(a)          # rdst_hip_sort: H2D, sort, D2H
+        assert same_bits(a, exp), dtype
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_sort_matches_oracle_over_sizes(gpu, oracle, dtype):
+    tile = 8192 if np.dtype(dtype).itemsize == 4 else 4096
+    sizes = [0, 1, 2, 3, 10, 100, 127, 128, 129, 5_000, tile - 1, tile, tile + 1, 2 * tile - 1, 2 * tile + 1, 50_000,
+             100_000, 300_000, 1_000_003, 5_000_011]
+    for i, n in enumerate(sizes):
+        a = random_bits(n, dtype, seed=100 + i).copy()
+        exp = a.copy()
+        oracle.sort(exp, threads=4)
+        got = _device_sort(gpu, a)
+        assert same_bits(got, exp), (dtype, n)
+        assert same_bits(exp, reference_sorted(a))  # oracle vs independent numpy, same input
+
+
+@pytest.mark.parametrize("dtype,shift", [("uint32", 16), ("uint64", 32), ("int32", 16), ("int64", 32)])
+def test_bimodal_shift_inputs(gpu, oracle, dtype, shift):
+    """gen_inputs (src/test_utils.rs:51-61): empty high / low levels -> level skipping on device."""
+    for n in (10_000, 500_000, 2_000_000):
+        a = gen_inputs(n, shift, dtype, seed=n)
+        exp = a.copy()
+        oracle.sort(exp, threads=4)
+        assert same_bits(_device_sort(gpu, a), exp), (dtype, n)
+
+
+def test_u32_patterns_on_device(gpu):
+    """validate_u32_patterns (src/test_utils.rs:148-262)."""
+    for a in u32_patterns():
+        assert np.array_equal(_device_sort(gpu, a), np.sort(a))
+
+
+@pytest.mark.parametrize("dtype", ["uint32", "uint64"])
+def test_degenerate_orders(gpu, dtype):
+    n = 1_000_000
+    base = random_bits(n, dtype, seed=1).copy()
+    for name, a in (("all_equal", np.full(n, 0xABCD1234, dtype=dtype)), ("sorted", np.sort(base)),
+                    ("reverse", np.sort(base)[::-1].copy()), ("two_values", (base & 1).astype(dtype)),
+                    ("one_digit_differs", (base & 0xFF00).astype(dtype))):
+        assert np.array_equal(_device_sort(gpu, a), np.sort(a)), name
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_float_specials(gpu, oracle, dtype):
+    sp = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, -np.nan, 1.0, -1.0, 5e-324, -5e-324, 1e30, -1e30], dtype=dtype)
+    a = np.tile(sp, 1000)
+    exp = a.copy()
+    oracle.sort(exp)
+    got = _device_sort(gpu, a)
+    assert same_bits(got, exp)
+    k = mapped_key(got)
+    assert (k[1:] >= k[:-1]).all() and np.isnan(got[0]) and np.signbit(got[0]) and np.isnan(got[-1])
+
+
+def test_unaligned_device_pointer(gpu, oracle):
+    """A slice that starts 4 bytes into an allocation: element-aligned only (scalar-load kernels)."""
+    import torch
+    a = random_bits(100_001, "uint32", seed=2).copy()
+    t = to_device(a)
+    view = t[1:]
+    assert view.data_ptr() % 16 != 0
+    gpu.sort_device_tensor(view)
+    got = to_host(t, "uint32")
+    exp = a[1:].copy()
+    oracle.sort(exp)
+    assert got[0] == a[0] and np.array_equal(got[1:], exp)
+
+
+# ---- parity hooks: K1 / K6 vs get_counts_with_ends, K3 vs out_of_place_sort ------------------
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_level_counts_hook_matches_oracle(gpu, oracle, dtype):
+    levels = np.dtype(dtype).itemsize
+    for n in (1, 1000, 400_001):
+        for a in (random_bits(n, dtype, seed=n).copy(), reference_sorted(random_bits(n, dtype, seed=n + 1))):
+            t = to_device(a)
+            allc = gpu.all_level_counts(t)
+            for level in range(levels):
+                c, srt, first, last = gpu.level_counts(t, level)
+                oc, osrt, ofirst, olast = oracle.get_counts_with_ends(a, level)
+                assert np.array_equal(np.asarray(c, dtype=np.uint64), oc), (dtype, n, level)
+                assert np.array_equal(allc[level], oc)
+                assert (srt, first, last) == (osrt, ofirst, olast), (dtype, n, level)
+    c, srt, first, last = gpu.level_counts(to_device(np.zeros(0, dtype=dtype)), 0)
+    assert sum(c) == 0 and srt and (first, last) == (0, 0)  # sort_utils.rs:116-118
+
+
+@pytest.mark.parametrize("dtype", ["uint32", "uint64", "float32", "int64"])
+def test_scatter_level_hook_is_the_reference_stable_pass(gpu, oracle, dtype):
+    """One K3 launch == out_of_place_sort on that digit, bit for bit (stability makes it unique)."""
+    levels = np.dtype(dtype).itemsize
+    for n in (2, 9, 8193, 250_000, 3_000_001):
+        a = random_bits(n, dtype, seed=n).copy()
+        t = to_device(a)
+        for level in (0, levels // 2, levels - 1):
+            dst, counts = gpu.scatter_level(t, level)
+            exp, _ = oracle.out_of_place_sort(a, level, "plain")
+            assert same_bits(to_host(dst, dtype), exp), (dtype, n, level)
+            oc, _, _, _ = oracle.get_counts_with_ends(a, level)
+            assert np.array_equal(counts, oc)
+        assert same_bits(to_host(t, dtype), a)  # source untouched
+
+
+def test_custom_tuner_round_trip(gpu):
+    """with_tuner: pick_algorithm sees the top-level histogram of the slice (src/sorter.rs:67-76)."""
+    from rdst_amd.tuner import Algorithm, StandardTuner, Tuner
+    seen = {}
+
+    class T(Tuner):
+        def pick_algorithm(self, p, counts):
+            seen["p"], seen["sum"] = p, sum(counts)
+            return Algorithm.GpuLsd
+
+    a = random_bits(200_000, "uint32", seed=8).copy()
+    t = to_device(a)
+    gpu.radix_sort_builder(t).with_tuner(T()).sort()
+    assert np.array_equal(to_host(t, "uint32"), np.sort(a))
+    assert seen["sum"] == 200_000 and seen["p"].level == 3 and seen["p"].parent_len is None
+    with pytest.raises(NotImplementedError):
+        gpu.radix_sort_builder(to_device(a)).with_tuner(StandardTuner()).sort()  # CPU algorithm: not shipped here
+
+
+def test_two_streams_share_the_workspace_safely(gpu):
+    import torch
+    a = random_bits(2_000_000, "uint32", seed=21).copy()
+    b = random_bits(2_000_000, "uint64", seed=22).copy()
+    ta, tb = to_device(a), to_device(b)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for _ in range(3):
+        with torch.cuda.stream(s1):
+            gpu.sort_device_tensor(ta, check=False)
+        with torch.cuda.stream(s2):
+            gpu.sort_device_tensor(tb, check=False)
+    torch.cuda.synchronize()
+    gpu.device_status()
+    assert np.array_equal(to_host(ta, "uint32"), np.sort(a)) and np.array_equal(to_host(tb, "uint64"), np.sort(b))
