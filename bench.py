@@ -35,12 +35,24 @@ ELEM = 4
 LEVELS = 4
 
 
+def effective_cpus():
+    """Host cores this process may really use: affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except Exception:  # noqa: BLE001
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(n_total):
     """Oracle (kind "port") on a bounded sample: ~10-20 s of CPU work."""
     import numpy as np
     from oracle import oracle as O
     O.load()
-    threads = os.cpu_count() or 1
+    threads = effective_cpus()
     rng = np.random.default_rng(SEED)
 
     def run(n):

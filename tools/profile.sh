@@ -1,0 +1,22 @@
+#!/bin/bash
+# Development aid: rocprofv3 kernel trace + PMC passes of bench.py on the GPU box.
+# usage: tools/profile.sh <tag> [extra bench args]
+set -u
+TAG=${1:-r01}; shift || true
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline $*"
+echo "== kernel trace"; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1 || echo "trace failed"
+for grp in "FETCH_SIZE" "WRITE_SIZE" \
+           "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
+           "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" \
+           "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" \
+           "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_WRITE_sum" "GRBM_GUI_ACTIVE"; do
+  name=$(echo $grp | tr ' ' '_' | cut -c1-40)
+  echo "== pmc $grp"
+  rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_$name -- $BENCH > $OUT/pmc_$name.log 2>&1 || echo "pmc $grp failed"
+done
+rocprofv3 -L > $OUT/counters.txt 2>&1 || true
+ls -R $OUT | head -50
