@@ -147,8 +147,9 @@ int rdst_pick_algorithm(int tuner_id, const rdst_tuning_params* p, const uint64_
 /* Bytes of device memory the workspace needs for a sort of `len` elements. */
 uint64_t rdst_hip_workspace_bytes(uint64_t len, uint32_t elem_bytes);
 
-/* Runtime knobs for experiments (scatter-kernel shape, histogram grid).  Values <= 0
- * restore the built-in choice.  Not part of the reference surface. */
+/* Runtime knobs for experiments: pass_config selects the scatter-kernel shape (tile size and
+ * LDS staging; negative = built-in default), hist_blocks_per_cu the histogram grid (<= 0 =
+ * built-in).  Not part of the reference surface. */
 int rdst_hip_set_tuning(int pass_config, int hist_blocks_per_cu);
 
 /* Per-kernel device timing for benchmarks.  While enabled, every pipeline (sort / hook call)

@@ -32,6 +32,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <mutex>
+#include <type_traits>
 #include <string>
 #include <vector>
 
@@ -51,6 +52,9 @@ template <typename S> struct StatusWord {
 // bounded spins: s_sleep(2) is ~128 clocks; 1<<22 polls is seconds, never reached in a healthy run
 constexpr uint32_t SPIN_LIMIT = 1u << 22;
 
+#ifndef RDST_LB_WINDOW
+#define RDST_LB_WINDOW 8  // predecessor status words fetched per look-back round trip
+#endif
 constexpr uint32_t ERR_LOOKBACK_TIMEOUT = 1;
 constexpr uint32_t ERR_SCATTER_RANGE = 2;  // a computed destination fell outside [0, n): never stored
 
@@ -210,20 +214,62 @@ __global__ __launch_bounds__(256) void scan_kernel(const unsigned long long* __r
 // predecessors have always started: forward progress of the look-back does not depend on the
 // order in which the hardware dispatches workgroups, nor on where (which XCD) they land.
 // Every cross-workgroup word is an agent-scope relaxed atomic whose value carries its own state
-// bits (no separate flag, hence no fence).  S = status word type: u32 while every prefix fits
-// 30 bits (n < 2^30), u64 above.
+// bits (no separate flag, hence no fence).
+//   S       status word: u32 while every prefix fits 30 bits (n < 2^30), u64 above
+//   MAPPED  key kind needs the order-preserving map (signed / float); unsigned keys skip it
+//   NARROW  n * sizeof(K) < 2^32: destinations are 32-bit byte offsets from a uniform base
 // ------------------------------------------------------------------------------------------
-template <typename K, typename S, int KPT, int NWAVES>
-__global__ __launch_bounds__(NWAVES * 64) void onesweep_kernel(
+
+#ifdef RDST_EXPERIMENTS
+__device__ uint32_t* g_exp_stats = nullptr;  // [tiles][4] look-back records of pass 0 (tools/ only)
+#endif
+
+// lanes below me holding my digit, 4 VALU per bit: my bit as a 0 / -1 mask (v_bfe_i32), the
+// wave's ballot of that bit (v_cmp), then per 32-lane half ONE v_bitop3_b32 that keeps in `same`
+// only the lanes whose bit equals mine:  same &= ~(ballot ^ my_bit)   (truth table 0x90).
+__device__ __forceinline__ uint32_t peers_below(uint32_t word, int bit0) {
+    uint32_t same_lo = ~0u, same_hi = ~0u;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const int m = __builtin_amdgcn_sbfe((int)word, (unsigned)(bit0 + b), 1u);  // 0 or -1
+        const uint64_t bal = __builtin_amdgcn_ballot_w64(m != 0);
+        same_lo = __builtin_amdgcn_bitop3_b32(same_lo, (uint32_t)bal, (uint32_t)m, 0x90);
+        same_hi = __builtin_amdgcn_bitop3_b32(same_hi, (uint32_t)(bal >> 32), (uint32_t)m, 0x90);
+    }
+    return __builtin_amdgcn_mbcnt_hi(same_hi, __builtin_amdgcn_mbcnt_lo(same_lo, 0u));
+}
+
+template <typename K>
+__device__ __forceinline__ uint32_t digit_word(K mapped, int shift) {  // 32-bit half that holds the digit
+    if constexpr (sizeof(K) == 8) return (uint32_t)(mapped >> (shift & 32));
+    else return (uint32_t)mapped;
+}
+
+// registers are capped so that the LDS-limited number of blocks per CU (3 at 32 KiB of staging,
+// more below) is not cut further by VGPRs: second launch-bound argument = waves per SIMD
+template <typename K, typename S, int KPT, int NWAVES, int STAGES, bool MAPPED, bool NARROW>
+__global__ __launch_bounds__(NWAVES * 64, (NWAVES * 64 * KPT * (int)sizeof(K) / STAGES > 32768 ? 2 : 3) * NWAVES / 4) void onesweep_kernel(
     K* __restrict__ buf_keys, K* __restrict__ buf_tmp, uint64_t n, int level,
     const uint64_t* __restrict__ base /* [256] of this level */, S* __restrict__ status /* [tiles][256] of this level */,
     uint32_t* __restrict__ ticket /* of this level */, const Plan* __restrict__ plan, uint32_t* __restrict__ err,
-    K neg, K pos) {
+    K neg, K pos, uint32_t ablate) {
+    // `ablate` is always 0 in the product build; tools/ builds with -DRDST_EXPERIMENTS can switch
+    // stages off to price them (results are then wrong by design, stores stay in range).
+#ifdef RDST_EXPERIMENTS
+#define RDST_ABL(bit) (((ablate) >> (bit)) & 1u)
+#else
+#define RDST_ABL(bit) false
+    (void)ablate;
+#endif
     constexpr int BLOCK = NWAVES * 64;
     constexpr int TILE = BLOCK * KPT;
+    constexpr int STAGE_KEYS = TILE / STAGES;  // keys staged through LDS at a time
+    constexpr int SPT = KPT / STAGES;          // slots each thread scatters per stage
     constexpr int SSHIFT = StatusWord<S>::SHIFT;
     constexpr S SMASK = StatusWord<S>::MASK;
+    using D = typename std::conditional<NARROW, uint32_t, uint64_t>::type;  // destination offset (bytes if NARROW, else elements)
     static_assert(BLOCK >= RADIX, "need one thread per digit");
+    static_assert(KPT % STAGES == 0 && (STAGES == 1 || TILE <= 65536), "stage split / 16-bit slot packing");
 
     if (plan->skip[level]) return;
     const bool from_tmp = plan->src_is_tmp[level] != 0;
@@ -232,15 +278,16 @@ __global__ __launch_bounds__(NWAVES * 64) void onesweep_kernel(
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* wave_hist = reinterpret_cast<uint32_t*>(smem);                          // [NWAVES][256]
-    uint64_t* s_delta = reinterpret_cast<uint64_t*>(smem + NWAVES * 1024);            // [256]
+    D* s_delta = reinterpret_cast<D*>(smem + NWAVES * 1024);                          // [256]
     uint32_t* s_misc = reinterpret_cast<uint32_t*>(smem + NWAVES * 1024 + 2048);      // [16]
-    K* s_keys = reinterpret_cast<K*>(smem + NWAVES * 1024 + 2048 + 64);               // [TILE]
+    K* s_keys = reinterpret_cast<K*>(smem + NWAVES * 1024 + 2048 + 64);               // [STAGE_KEYS]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int shift = level * 8;
+    const int bit0 = shift & 31;
 
     if (tid == 0) {
-        s_misc[0] = atomicAdd(ticket, 1u);
+        s_misc[0] = RDST_ABL(4) ? blockIdx.x : atomicAdd(ticket, 1u);
         s_misc[1] = 0;  // block-wide failure flag
     }
     __syncthreads();
@@ -248,6 +295,7 @@ __global__ __launch_bounds__(NWAVES * 64) void onesweep_kernel(
     const uint64_t tile_begin = (uint64_t)t * TILE;
     if (tile_begin >= n) return;
     const uint32_t valid = (n - tile_begin < (uint64_t)TILE) ? (uint32_t)(n - tile_begin) : (uint32_t)TILE;
+    const bool full = valid == (uint32_t)TILE;
     S* row = status + (size_t)t * RADIX;
 
     // 1. load, wave-striped: lane l of wave w takes keys w*64*KPT + i*64 + l (256 contiguous
@@ -256,18 +304,25 @@ __global__ __launch_bounds__(NWAVES * 64) void onesweep_kernel(
     {
         const K* tsrc = src + tile_begin;
         const uint32_t wbase = (uint32_t)wave * 64u * KPT + (uint32_t)lane;
-        if (valid == (uint32_t)TILE) {
+        if (full) {
 #pragma unroll
             for (int i = 0; i < KPT; ++i) mk[i] = tsrc[wbase + i * 64];
+            if constexpr (MAPPED) {
 #pragma unroll
-            for (int i = 0; i < KPT; ++i) mk[i] = map_key<K>(mk[i], neg, pos);
+                for (int i = 0; i < KPT; ++i) mk[i] = map_key<K>(mk[i], neg, pos);
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < KPT; ++i) {
                 const uint32_t idx = wbase + i * 64;
                 // out-of-range slots: mapped key all ones -> digit 255, ranked after every
                 // real key of the tile, never stored
-                mk[i] = (idx < valid) ? map_key<K>(tsrc[idx], neg, pos) : (K)~(K)0;
+                K v = (K)~(K)0;
+                if (idx < valid) {
+                    v = tsrc[idx];
+                    if constexpr (MAPPED) v = map_key<K>(v, neg, pos);
+                }
+                mk[i] = v;
             }
         }
     }
@@ -317,71 +372,154 @@ __global__ __launch_bounds__(NWAVES * 64) void onesweep_kernel(
     }
     __syncthreads();
 
-    // 5. stable rank inside the wave: lanes with my digit and a lower lane id go first;
-    //    rounds i go in order; the running slot lives in this wave's LDS row
-    uint32_t posn[KPT];
+    // 5. stable rank inside the wave: lanes with my digit and a lower lane id go first; rounds
+    //    go in order.  The running slot of (wave, digit) lives in LDS: every lane reads it, then
+    //    every lane adds one (LDS operations of one wave execute in program order), so after the
+    //    round it has advanced by the size of the digit's group.
+    //    STAGES == 1: the key goes straight to its slot of the LDS staging buffer (step 6).
+    //    STAGES  > 1: the tile is larger than the staging buffer; slots are kept (16-bit pairs).
+    uint32_t slots[STAGES > 1 ? KPT / 2 : 1];
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
-        const uint32_t d = digit_of(mk[i], shift);
-        const uint64_t peers = match_any8(d);
-        const uint32_t below = lanes_below(peers);
-        const uint32_t b = wh[d];
+        uint32_t* slot = &wh[digit_of(mk[i], shift)];
+        const uint32_t b = *slot;
+        const uint32_t below = RDST_ABL(3) ? 0u : peers_below(digit_word<K>(mk[i], shift), bit0);
         __builtin_amdgcn_wave_barrier();
-        if (below == 0) wh[d] = b + (uint32_t)__popcll(peers);
-        __builtin_amdgcn_wave_barrier();
-        posn[i] = b + below;
+        atomicAdd(slot, 1u);
+        if constexpr (STAGES == 1) {
+            s_keys[b + below] = mk[i];
+        } else {
+            uint32_t sl = b + below;
+            // pin the slot here: its inputs are eight ballots (SGPR pairs); left alone the
+            // compiler sinks the arithmetic to the first use, after the look-back, and keeps
+            // every round's ballots alive (KPT * 8 SGPR pairs -> spills)
+            asm volatile("" : "+v"(sl));
+            if (i & 1) slots[i >> 1] |= sl << 16;
+            else slots[i >> 1] = sl;
+        }
     }
 
-    // 6. keys into LDS in tile-sorted order
-#pragma unroll
-    for (int i = 0; i < KPT; ++i) s_keys[posn[i]] = mk[i];
-
-    // 7. decoupled look-back over the earlier tiles (thread d walks digit d)
+    // 7. decoupled look-back over the earlier tiles (thread d walks digit d).  The walk is the
+    //    latency chain of the whole pass (each round trip crosses the fabric), so LB_WINDOW
+    //    predecessor words are fetched at once and then consumed in order.
     if (tid < RADIX) {
         uint64_t excl = 0;
         bool fail = false;
-        if (t > 0) {
-            const S* p = row - RADIX + tid;
+        if (t > 0 && !RDST_ABL(0)) {
+            constexpr int LB_WINDOW = RDST_LB_WINDOW;
+            int64_t prev = (int64_t)t - 1;  // next tile whose word is still to be consumed
             uint32_t spins = 0;
-            for (;;) {
-                const S v = ld_relaxed<S>(p);
-                const uint32_t st = (uint32_t)(v >> SSHIFT);
-                if (st == ST_EMPTY) {
+            bool done = false;
+#ifdef RDST_EXPERIMENTS
+            const uint64_t lb_t0 = __builtin_amdgcn_s_memtime();
+            uint32_t lb_iters = 0;
+#endif
+            while (!done) {
+#ifdef RDST_EXPERIMENTS
+                ++lb_iters;
+#endif
+                S v[LB_WINDOW];
+#pragma unroll
+                for (int k = 0; k < LB_WINDOW; ++k) {
+                    const int64_t idx = prev - k;
+                    // tile 0 is always INCL, so an index below 0 is never consumed
+                    v[k] = idx >= 0 ? ld_relaxed<S>(status + (size_t)idx * RADIX + tid) : ((S)ST_INCL << SSHIFT);
+                }
+                bool blocked = false;
+                int consumed = 0;
+#pragma unroll
+                for (int k = 0; k < LB_WINDOW; ++k) {
+                    const uint32_t st = (uint32_t)(v[k] >> SSHIFT);
+                    if (!done && !blocked) {
+                        if (st == ST_EMPTY) {
+                            blocked = true;
+                        } else {
+                            excl += (uint64_t)(v[k] & SMASK);
+                            ++consumed;
+                            done = st == ST_INCL;
+                        }
+                    }
+                }
+                prev -= consumed;
+                if (blocked && !done) {
                     __builtin_amdgcn_s_sleep(2);
                     ++spins;
-                    if (spins > SPIN_LIMIT || ((spins & 1023u) == 0 && ld_relaxed<uint32_t>(err) != 0)) {
+                    if (spins > SPIN_LIMIT || ((spins & 255u) == 0 && ld_relaxed<uint32_t>(err) != 0)) {
                         fail = true;
                         break;
                     }
-                    continue;
                 }
-                excl += (uint64_t)(v & SMASK);
-                if (st == ST_INCL) break;
-                p -= RADIX;  // tile 0 is always INCL, so the walk stays inside the array
             }
             if (!fail) st_relaxed<S>(&row[tid], ((S)ST_INCL << SSHIFT) | ((S)(excl + pub) & SMASK));
+#ifdef RDST_EXPERIMENTS
+            if (tid == 0 && g_exp_stats && level == 0) {  // digit 0's walker, one record per tile, no atomics
+                uint32_t* rec = g_exp_stats + (size_t)t * 4;
+                rec[0] = lb_iters;
+                rec[1] = spins;
+                rec[2] = (uint32_t)((int64_t)t - 1 - prev);
+                rec[3] = (uint32_t)(__builtin_amdgcn_s_memtime() - lb_t0);
+            }
+#endif
         }
         if (fail) {
             atomicOr(err, ERR_LOOKBACK_TIMEOUT);
             s_misc[1] = 1;
         }
-        s_delta[tid] = base[tid] + excl - (uint64_t)local_off;
+        const uint64_t first = base[tid] + excl - (uint64_t)local_off;  // dst index of tile slot 0 of digit d (mod 2^64)
+        if constexpr (NARROW) s_delta[tid] = (uint32_t)first * (uint32_t)sizeof(K);
+        else s_delta[tid] = first;
     }
     __syncthreads();
     if (s_misc[1]) return;  // never store with an unknown prefix
 
-    // 8. scatter: consecutive threads hold consecutive slots of a digit's run
+    // 6 + 8. per stage: (STAGES > 1) keys whose slot falls into the stage go to the LDS buffer;
+    //    then consecutive threads take consecutive slots of a digit's run and store them.  LDS
+    //    reads are batched (keys, then per-digit destinations) so their latencies overlap.
+    bool bad = false;
 #pragma unroll
-    for (int i = 0; i < KPT; ++i) {
-        const uint32_t p = (uint32_t)tid + (uint32_t)i * BLOCK;
-        const K k = s_keys[p];
-        const uint32_t d = digit_of(k, shift);
-        if (p < valid) {
-            const uint64_t g = s_delta[d] + p;
-            if (g < n) dst[g] = unmap_key<K>(k, neg, pos);
-            else atomicOr(err, ERR_SCATTER_RANGE);  // cannot happen with consistent counts; keeps a logic error from faulting
+    for (int stage = 0; stage < STAGES; ++stage) {
+        if constexpr (STAGES > 1) {
+            if (stage > 0) __syncthreads();  // previous stage's slots have all been read
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                const uint32_t sl = (i & 1) ? (slots[i >> 1] >> 16) : (slots[i >> 1] & 0xFFFFu);
+                const uint32_t rel = sl - (uint32_t)(stage * STAGE_KEYS);
+                if (rel < (uint32_t)STAGE_KEYS) s_keys[rel] = mk[i];
+            }
+            __syncthreads();
+        }
+        K kk[SPT];
+        D dd[SPT];
+#pragma unroll
+        for (int i = 0; i < SPT; ++i) kk[i] = s_keys[tid + i * BLOCK];
+#pragma unroll
+        for (int i = 0; i < SPT; ++i) dd[i] = s_delta[digit_of(kk[i], shift)];
+#pragma unroll
+        for (int i = 0; i < SPT; ++i) {
+            const uint32_t p = (uint32_t)(stage * STAGE_KEYS) + (uint32_t)tid + (uint32_t)i * BLOCK;  // slot in the tile
+            K out = kk[i];
+            if constexpr (MAPPED) out = unmap_key<K>(out, neg, pos);
+            if (RDST_ABL(1) && out != (K)0x12345) continue;  // no stores
+            if (RDST_ABL(2)) {                                // sequential stores instead of the scatter
+                if (full || p < valid) dst[tile_begin + p] = out;
+                continue;
+            }
+            if constexpr (NARROW) {
+                const uint32_t g = dd[i] + p * (uint32_t)sizeof(K);  // byte offset, < 2^32
+                const bool ok = g < (uint32_t)n * (uint32_t)sizeof(K);
+                bad |= !ok && (full || p < valid);
+                if (ok && (full || p < valid)) *reinterpret_cast<K*>(reinterpret_cast<unsigned char*>(dst) + g) = out;
+            } else {
+                const uint64_t g = dd[i] + p;
+                const bool ok = g < n;
+                bad |= !ok && (full || p < valid);
+                if (ok && (full || p < valid)) dst[g] = out;
+            }
         }
     }
+    // cannot happen with consistent counts; the range test keeps a logic error from faulting
+    if (bad) atomicOr(err, ERR_SCATTER_RANGE);
+#undef RDST_ABL
 }
 
 // result sits in tmp after an odd number of executed passes: copy back
@@ -445,16 +583,22 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
         if (e__ != hipSuccess) return fail(RDST_ERR_HIP, #expr, e__);   \
     } while (0)
 
-struct PassCfg { int nwaves, kpt4, kpt8; };
+struct PassCfg { int nwaves, kpt4, kpt8, stages; };
 constexpr PassCfg kPassCfgs[] = {
-    {8, 16, 8},    // 0: 512 threads, 8192 / 4096 keys per tile (32 KiB of keys)
-    {16, 16, 8},   // 1: 1024 threads, 16384 / 8192
-    {4, 16, 8},    // 2: 256 threads, 4096 / 2048
-    {8, 24, 12},   // 3: 512 threads, 12288 / 6144
+    {8, 16, 8, 1},    // 0: 512 threads,  8192 / 4096 keys per tile, whole tile staged (32 KiB)
+    {8, 32, 16, 2},   // 1: 512 threads, 16384 / 8192 keys per tile, staged in two halves (32 KiB)
+    {8, 24, 12, 2},   // 2: 512 threads, 12288 / 6144 keys per tile, two halves (24 KiB)
+    {8, 24, 12, 1},   // 3: 512 threads, 12288 / 6144 keys per tile, whole tile staged (48 KiB)
+    {8, 16, 8, 2},    // 4: 512 threads,  8192 / 4096 keys per tile, two halves (16 KiB)
+    {4, 32, 16, 2},   // 5: 256 threads,  8192 / 4096 keys per tile, two halves (16 KiB)
 };
 constexpr int kNumPassCfgs = sizeof(kPassCfgs) / sizeof(kPassCfgs[0]);
 
-struct Tuning { int pass_cfg = 0; int hist_bpc = 0; bool profiling = false; };
+struct Tuning { int pass_cfg = 2; int hist_bpc = 0; bool profiling = false; };
+uint32_t g_ablate = 0;  // only ever set by the RDST_EXPERIMENTS build
+#ifdef RDST_EXPERIMENTS
+size_t g_exp_lds_total = 0;
+#endif
 Tuning g_tuning;
 std::mutex g_mutex;
 
@@ -497,7 +641,7 @@ Layout make_layout(uint64_t n, uint32_t elem_bytes, uint32_t levels, int cfg) {
     if (L.tiles == 0) L.tiles = 1;
     L.status_bytes = n < (1ull << 30) ? 4 : 8;  // an inclusive prefix can reach n
     size_t o = 0;
-    L.off_err = o; o += 16;
+    L.off_err = o; o += 64;  // error word + (experiments build) look-back statistics
     L.off_tickets = o; o += sizeof(uint32_t) * MAX_LEVELS;
     L.off_plan = o; o += align_up(sizeof(Plan), 16);
     L.off_hist = o; o += sizeof(uint64_t) * (size_t)levels * RADIX;
@@ -594,15 +738,24 @@ int launch_hist(const K* keys, uint64_t n, uint32_t blocks, KeyMap km, unsigned 
     return RDST_OK;
 }
 
-template <typename K, typename S, int KPT, int NWAVES>
+template <typename K, typename S, int KPT, int NWAVES, int STAGES, bool MAPPED, bool NARROW>
 int launch_pass_t(K* keys, K* tmp, uint64_t n, int level, const Layout& L, char* ws, KeyMap km, hipStream_t s) {
     constexpr int TILE = NWAVES * 64 * KPT;
-    const size_t lds = (size_t)NWAVES * 1024 + 2048 + 64 + sizeof(K) * TILE;
+    size_t lds = (size_t)NWAVES * 1024 + 2048 + 64 + sizeof(K) * (TILE / STAGES);
+#ifdef RDST_EXPERIMENTS
+    if (g_exp_lds_total > lds) lds = g_exp_lds_total;  // fewer blocks per CU
+    static size_t attr_lds = 0;
+    const bool attr_set = attr_lds == lds;
+    attr_lds = lds;
+#else
     static bool attr_set = false;
+#endif
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&onesweep_kernel<K, S, KPT, NWAVES>),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&onesweep_kernel<K, S, KPT, NWAVES, STAGES, MAPPED, NARROW>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#ifndef RDST_EXPERIMENTS
         attr_set = true;
+#endif
     }
     const uint64_t* base = reinterpret_cast<const uint64_t*>(ws + L.off_base) + (size_t)level * RADIX;
     S* status = reinterpret_cast<S*>(ws + L.off_status) + (size_t)level * L.tiles * RADIX;
@@ -610,36 +763,40 @@ int launch_pass_t(K* keys, K* tmp, uint64_t n, int level, const Layout& L, char*
     const Plan* plan = reinterpret_cast<const Plan*>(ws + L.off_plan);
     uint32_t* err = reinterpret_cast<uint32_t*>(ws + L.off_err);
     const dim3 grid((uint32_t)L.tiles), block(NWAVES * 64);
-    hipLaunchKernelGGL((onesweep_kernel<K, S, KPT, NWAVES>), grid, block, lds, s, keys, tmp, n, level, base, status,
-                       ticket, plan, err, (K)km.neg, (K)km.pos);
+    hipLaunchKernelGGL((onesweep_kernel<K, S, KPT, NWAVES, STAGES, MAPPED, NARROW>), grid, block, lds, s, keys, tmp, n,
+                       level, base, status, ticket, plan, err, (K)km.neg, (K)km.pos, g_ablate);
     HIP_TRY(hipGetLastError());
     return RDST_OK;
 }
 
-template <typename K, typename S>
+template <typename K, typename S, bool MAPPED, bool NARROW>
 int launch_pass_s(int cfg, K* keys, K* tmp, uint64_t n, int level, const Layout& L, char* ws, KeyMap km, hipStream_t s) {
-    if constexpr (sizeof(K) == 4) {
-        switch (cfg) {
-            case 0: return launch_pass_t<K, S, 16, 8>(keys, tmp, n, level, L, ws, km, s);
-            case 1: return launch_pass_t<K, S, 16, 16>(keys, tmp, n, level, L, ws, km, s);
-            case 2: return launch_pass_t<K, S, 16, 4>(keys, tmp, n, level, L, ws, km, s);
-            case 3: return launch_pass_t<K, S, 24, 8>(keys, tmp, n, level, L, ws, km, s);
-        }
-    } else {
-        switch (cfg) {
-            case 0: return launch_pass_t<K, S, 8, 8>(keys, tmp, n, level, L, ws, km, s);
-            case 1: return launch_pass_t<K, S, 8, 16>(keys, tmp, n, level, L, ws, km, s);
-            case 2: return launch_pass_t<K, S, 8, 4>(keys, tmp, n, level, L, ws, km, s);
-            case 3: return launch_pass_t<K, S, 12, 8>(keys, tmp, n, level, L, ws, km, s);
-        }
+    constexpr int F = sizeof(K) == 4 ? 2 : 1;  // 4-byte keys: twice the keys per thread, same bytes
+    switch (cfg) {
+        case 0: return launch_pass_t<K, S, 8 * F, 8, 1, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, s);
+        case 1: return launch_pass_t<K, S, 16 * F, 8, 2, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, s);
+        case 2: return launch_pass_t<K, S, 12 * F, 8, 2, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, s);
+        case 3: return launch_pass_t<K, S, 12 * F, 8, 1, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, s);
+        case 4: return launch_pass_t<K, S, 8 * F, 8, 2, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, s);
+        case 5: return launch_pass_t<K, S, 16 * F, 4, 2, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, s);
     }
     return fail(RDST_ERR_ARG, "bad pass config");
 }
 
 template <typename K>
 int launch_pass(int cfg, K* keys, K* tmp, uint64_t n, int level, const Layout& L, char* ws, KeyMap km, hipStream_t s) {
-    if (L.status_bytes == 4) return launch_pass_s<K, uint32_t>(cfg, keys, tmp, n, level, L, ws, km, s);
-    return launch_pass_s<K, unsigned long long>(cfg, keys, tmp, n, level, L, ws, km, s);
+    const bool mapped = km.neg != 0 || km.pos != 0;
+    const bool narrow = n * sizeof(K) < (1ull << 32);
+    if (L.status_bytes == 4) {
+        if (narrow) {
+            return mapped ? launch_pass_s<K, uint32_t, true, true>(cfg, keys, tmp, n, level, L, ws, km, s)
+                          : launch_pass_s<K, uint32_t, false, true>(cfg, keys, tmp, n, level, L, ws, km, s);
+        }
+        return mapped ? launch_pass_s<K, uint32_t, true, false>(cfg, keys, tmp, n, level, L, ws, km, s)
+                      : launch_pass_s<K, uint32_t, false, false>(cfg, keys, tmp, n, level, L, ws, km, s);
+    }
+    return mapped ? launch_pass_s<K, unsigned long long, true, false>(cfg, keys, tmp, n, level, L, ws, km, s)
+                  : launch_pass_s<K, unsigned long long, false, false>(cfg, keys, tmp, n, level, L, ws, km, s);
 }
 
 // The whole device-side pipeline for levels [level_lo, level_hi): memset, K1, K2, passes,
@@ -652,7 +809,7 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     int rc = current_device_state(&D);
     if (rc) return rc;
     int cfg = g_tuning.pass_cfg;
-    if (cfg < 0 || cfg >= kNumPassCfgs) cfg = 0;
+    if (cfg < 0 || cfg >= kNumPassCfgs) cfg = 2;
     const Layout L = make_layout(n, sizeof(K), LEVELS, cfg);
     if (L.tiles >= (1ull << 31)) return fail(RDST_ERR_ARG, "len too large for one launch");
     rc = ensure_workspace(*D, L.total);
@@ -747,10 +904,31 @@ int rdst_hip_abi_version(void) { return RDST_HIP_ABI_VERSION; }
 int rdst_hip_set_tuning(int pass_config, int hist_blocks_per_cu) {
     std::lock_guard<std::mutex> lock(g_mutex);
     if (pass_config >= kNumPassCfgs) return fail(RDST_ERR_ARG, "tuning value out of range");
-    g_tuning.pass_cfg = pass_config > 0 ? pass_config : 0;
+    g_tuning.pass_cfg = pass_config >= 0 ? pass_config : 2;
     g_tuning.hist_bpc = hist_blocks_per_cu > 0 ? hist_blocks_per_cu : 0;
     return RDST_OK;
 }
+
+#ifdef RDST_EXPERIMENTS
+int rdst_hip_exp_set_ablation(uint32_t mask) { g_ablate = mask; return 0; }
+int rdst_hip_exp_set_lds(uint32_t bytes) { g_exp_lds_total = bytes; return 0; }
+// per-tile look-back records of level 0: windows fetched, blocked re-polls, tiles consumed, shader clocks
+int rdst_hip_exp_stats(uint32_t* host_out, uint64_t tiles) {
+    static uint32_t* dev = nullptr;
+    static uint64_t cap = 0;
+    if (host_out == nullptr) {  // arm: (re)allocate and clear
+        if (cap < tiles) {
+            if (dev) (void)hipFree(dev);
+            if (hipMalloc((void**)&dev, tiles * 16) != hipSuccess) return -1;
+            cap = tiles;
+        }
+        if (hipMemset(dev, 0, tiles * 16) != hipSuccess) return -1;
+        return hipMemcpyToSymbol(HIP_SYMBOL(g_exp_stats), &dev, sizeof dev) == hipSuccess ? 0 : -1;
+    }
+    if (hipDeviceSynchronize() != hipSuccess || !dev) return -1;
+    return hipMemcpy(host_out, dev, tiles * 16, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int rdst_hip_set_profiling(int enabled) {
     std::lock_guard<std::mutex> lock(g_mutex);

@@ -220,7 +220,7 @@ def radix_sort_unstable(data) -> None:
     radix_sort_builder(data).sort()
 
 
-def set_tuning(pass_config=0, hist_blocks_per_cu=0):
+def set_tuning(pass_config=-1, hist_blocks_per_cu=0):
     _lib.check(_lib.load().rdst_hip_set_tuning(int(pass_config), int(hist_blocks_per_cu)))
 
 

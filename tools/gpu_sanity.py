@@ -98,7 +98,7 @@ def time_sort(n, dtype, iters=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true")
-    ap.add_argument("--cfg", type=int, default=0)
+    ap.add_argument("--cfg", type=int, default=-1)
     ap.add_argument("--skip-small", action="store_true")
     args = ap.parse_args()
     print(torch.cuda.get_device_name(0), flush=True)
