@@ -110,30 +110,48 @@ __device__ __forceinline__ uint32_t lanes_below(uint64_t mask) {  // popcount(ma
 }
 
 // ------------------------------------------------------------------------------------------
-// K1: every level's histogram from one read.  block = 256, grid-contiguous pieces.
-// Per-wave 256-bin histograms in LDS (one copy per wave and level), block reduce, one global
-// atomic per non-empty (level, digit).  VEC = keys per 16-byte load (1 = unaligned fallback).
+// K1: every level's histogram from one read.  One 1024-thread block per CU (grid = #CUs), each
+// sweeping a contiguous piece with 16-byte loads, four in flight per lane.
+//
+// LDS atomics on a plain [level][digit] table are bank-bound on uniform keys: the 32 lanes of a
+// half-wave pick 32 random banks, ~3.5 of them collide on the busiest bank, and the first version
+// of this kernel sat at 72 % conflict cycles (profiles/r01a_pmc_summary.json).  So the table is
+// replicated COPIES times along the bank axis — word (level*256 + digit)*COPIES + (lane % COPIES)
+// — which puts lane l of a half-wave on bank l: no two lanes of one LDS cycle share a bank
+// (COPIES = 32; with 16 copies for 8-byte keys two lanes can, at most 2-way).  128 KiB of LDS.
+// The copies are folded (rotated reads, conflict-free) and added to the global table at the end.
+// VEC = keys per 16-byte load (1 = unaligned fallback).
 // ------------------------------------------------------------------------------------------
+constexpr int HIST_THREADS = 1024;
+
 template <typename K, int LEVELS, int VEC>
-__global__ __launch_bounds__(256) void hist_kernel(const K* __restrict__ keys, uint64_t n, K neg, K pos,
-                                                   unsigned long long* __restrict__ hist) {
-    __shared__ uint32_t s_h[4][LEVELS][RADIX];
-    const int tid = threadIdx.x, wave = tid >> 6;
-    for (int i = tid; i < 4 * LEVELS * RADIX; i += 256) (&s_h[0][0][0])[i] = 0;
+__global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const K* __restrict__ keys, uint64_t n, K neg, K pos,
+                                                            unsigned long long* __restrict__ hist) {
+    constexpr int COPIES = LEVELS <= 4 ? 32 : 16;
+    constexpr int WORDS = LEVELS * RADIX * COPIES;  // 32768 words = 128 KiB
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* s_h = reinterpret_cast<uint32_t*>(smem);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < WORDS; i += HIST_THREADS) s_h[i] = 0;
     __syncthreads();
 
-    constexpr uint64_t GRAN = 256ull * VEC * 4;  // one unrolled sweep of the block
+    constexpr uint64_t GRAN = (uint64_t)HIST_THREADS * VEC * 4;  // one unrolled sweep of the block
     uint64_t piece = (n + gridDim.x - 1) / gridDim.x;
     piece = (piece + GRAN - 1) / GRAN * GRAN;
     const uint64_t p_begin = (uint64_t)blockIdx.x * piece;
     uint64_t p_end = p_begin + piece;
     if (p_end > n) p_end = n;
-    uint32_t(*wh)[RADIX] = s_h[wave];
+    uint32_t* mine = s_h + (tid & (COPIES - 1));  // my bank column
+
+    auto count = [&](K raw) {
+        const K m = map_key<K>(raw, neg, pos);
+#pragma unroll
+        for (int l = 0; l < LEVELS; ++l) atomicAdd(&mine[(l * RADIX + digit_of(m, l * 8)) * COPIES], 1u);
+    };
 
     struct alignas(sizeof(K) * VEC) V { K e[VEC]; };
     uint64_t i = p_begin + (uint64_t)tid * VEC;
-    constexpr uint64_t STRIDE = 256ull * VEC;
-    // full sweeps: 4 independent 16-byte loads in flight per lane
+    constexpr uint64_t STRIDE = (uint64_t)HIST_THREADS * VEC;
     for (; i + 3 * STRIDE + VEC <= p_end; i += 4 * STRIDE) {
         V v[4];
 #pragma unroll
@@ -141,27 +159,20 @@ __global__ __launch_bounds__(256) void hist_kernel(const K* __restrict__ keys, u
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                const K m = map_key<K>(v[u].e[e], neg, pos);
-#pragma unroll
-                for (int l = 0; l < LEVELS; ++l) atomicAdd(&wh[l][digit_of(m, l * 8)], 1u);
-            }
+            for (int e = 0; e < VEC; ++e) count(v[u].e[e]);
     }
-    // remainder of the piece, element-wise
-    for (; i < p_end; i += STRIDE) {
+    for (; i < p_end; i += STRIDE) {  // remainder of the piece, element-wise
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            if (i + e < p_end) {
-                const K m = map_key<K>(keys[i + e], neg, pos);
-#pragma unroll
-                for (int l = 0; l < LEVELS; ++l) atomicAdd(&wh[l][digit_of(m, l * 8)], 1u);
-            }
-        }
+        for (int e = 0; e < VEC; ++e)
+            if (i + e < p_end) count(keys[i + e]);
     }
     __syncthreads();
-    for (int j = tid; j < LEVELS * RADIX; j += 256) {
-        const int l = j >> 8, d = j & 255;
-        const uint32_t c = s_h[0][l][d] + s_h[1][l][d] + s_h[2][l][d] + s_h[3][l][d];
+    // fold the copies: thread j owns (level, digit) pair j (+1024, ...); reading copy (c + j) % COPIES
+    // in step c keeps the lanes of a half-wave on distinct banks
+    for (int j = tid; j < LEVELS * RADIX; j += HIST_THREADS) {
+        uint32_t c = 0;
+#pragma unroll 8
+        for (int k = 0; k < COPIES; ++k) c += s_h[j * COPIES + ((k + j) & (COPIES - 1))];
         if (c) atomicAdd(&hist[j], (unsigned long long)c);
     }
 }
@@ -725,17 +736,26 @@ KeyMap key_map_for(rdst_key_kind kind, uint32_t elem_bytes) {
     }
 }
 
-template <typename K, int LEVELS>
-int launch_hist(const K* keys, uint64_t n, uint32_t blocks, KeyMap km, unsigned long long* hist, hipStream_t s) {
-    const dim3 grid(blocks), block(256);
-    const bool aligned = (reinterpret_cast<uintptr_t>(keys) & 15u) == 0;
-    constexpr int VEC = 16 / sizeof(K);
-    if (aligned)
-        hipLaunchKernelGGL((hist_kernel<K, LEVELS, VEC>), grid, block, 0, s, keys, n, (K)km.neg, (K)km.pos, hist);
-    else
-        hipLaunchKernelGGL((hist_kernel<K, LEVELS, 1>), grid, block, 0, s, keys, n, (K)km.neg, (K)km.pos, hist);
+template <typename K, int LEVELS, int VEC>
+int launch_hist_v(const K* keys, uint64_t n, uint32_t blocks, KeyMap km, unsigned long long* hist, hipStream_t s) {
+    constexpr size_t lds = (size_t)LEVELS * RADIX * (LEVELS <= 4 ? 32 : 16) * sizeof(uint32_t);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&hist_kernel<K, LEVELS, VEC>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((hist_kernel<K, LEVELS, VEC>), dim3(blocks), dim3(HIST_THREADS), lds, s, keys, n, (K)km.neg,
+                       (K)km.pos, hist);
     HIP_TRY(hipGetLastError());
     return RDST_OK;
+}
+
+template <typename K, int LEVELS>
+int launch_hist(const K* keys, uint64_t n, uint32_t blocks, KeyMap km, unsigned long long* hist, hipStream_t s) {
+    const bool aligned = (reinterpret_cast<uintptr_t>(keys) & 15u) == 0;
+    if (aligned) return launch_hist_v<K, LEVELS, 16 / sizeof(K)>(keys, n, blocks, km, hist, s);
+    return launch_hist_v<K, LEVELS, 1>(keys, n, blocks, km, hist, s);
 }
 
 template <typename K, typename S, int KPT, int NWAVES, int STAGES, bool MAPPED, bool NARROW>
@@ -828,9 +848,9 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     if (status_hi > status_lo) HIP_TRY(hipMemsetAsync(ws + status_lo, 0, status_hi - status_lo, s));
     if ((rc = prof_mark(*D, s))) return rc;
 
-    // K1: enough blocks to fill the chip several times over, but no more than the data needs
-    uint64_t blocks = (uint64_t)(g_tuning.hist_bpc > 0 ? g_tuning.hist_bpc : 8) * D->cus;
-    const uint64_t per_block_min = 256ull * (16 / sizeof(K)) * 4;
+    // K1: one 128-KiB-LDS block per CU (more only on request), but no more than the data needs
+    uint64_t blocks = (uint64_t)(g_tuning.hist_bpc > 0 ? g_tuning.hist_bpc : 1) * D->cus;
+    const uint64_t per_block_min = (uint64_t)HIST_THREADS * (16 / sizeof(K)) * 4;
     const uint64_t max_useful = (n + per_block_min - 1) / per_block_min;
     if (blocks > max_useful) blocks = max_useful;
     if (blocks < 1) blocks = 1;
