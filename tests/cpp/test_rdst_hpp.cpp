@@ -1,0 +1,62 @@
+// C++ caller of include/rdst.hpp, written like the reference's own unit tests
+// (src/radix_sort.rs:146-340: random input, compare with the standard library's sort).
+// Built and run by tests/test_cpp_mirror.py.  Exit code 0 = all checks passed.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <vector>
+
+#include "rdst.hpp"
+
+template <typename T, typename U>
+static bool same_bits(const std::vector<T>& a, const std::vector<T>& b) {
+    return a.size() == b.size() && (a.empty() || std::memcmp(a.data(), b.data(), a.size() * sizeof(T)) == 0);
+}
+
+template <typename T>
+static int check_int(std::size_t n, unsigned seed) {
+    std::mt19937_64 rng(seed);
+    std::vector<T> v(n);
+    for (auto& x : v) x = static_cast<T>(rng());
+    std::vector<T> expect = v;
+    std::sort(expect.begin(), expect.end());  // reference oracle: std sort (src/test_utils.rs:119)
+    rdst::radix_sort_unstable(v);
+    return same_bits<T, T>(v, expect) ? 0 : 1;
+}
+
+template <typename T, typename U>
+static int check_float(std::size_t n, unsigned seed) {
+    std::mt19937_64 rng(seed);
+    std::vector<T> v(n);
+    for (auto& x : v) { U b = static_cast<U>(rng()); std::memcpy(&x, &b, sizeof b); }  // any bit pattern
+    std::vector<T> expect = v;
+    auto key = [](T f) { U u; std::memcpy(&u, &f, sizeof u); const U msb = U(1) << (sizeof(U) * 8 - 1); return (u & msb) ? U(~u) : U(u ^ msb); };
+    std::sort(expect.begin(), expect.end(), [&](T a, T b) { return key(a) < key(b); });  // total_cmp order (src/radix_sort.rs:97-144)
+    rdst::radix_sort_builder(v).with_parallel(false).sort();
+    return same_bits<T, U>(v, expect) ? 0 : 1;
+}
+
+int main() {
+    int bad = 0;
+    std::vector<std::uint32_t> doc = {3, 1, 2};  // src/radix_sort.rs:11-14
+    rdst::radix_sort_unstable(doc);
+    bad += !(doc == std::vector<std::uint32_t>{1, 2, 3});
+    std::vector<std::uint32_t> simple = {55, 22, 73, 4, 89, 0, 100, 3};  // examples/simple_usage.rs:4-7
+    rdst::radix_sort_unstable(simple);
+    bad += !(simple == std::vector<std::uint32_t>{0, 3, 4, 22, 55, 73, 89, 100});
+    for (std::size_t n : {0ul, 1ul, 2ul, 129ul, 100000ul, 3000001ul}) {
+        bad += check_int<std::uint32_t>(n, 1) + check_int<std::uint64_t>(n, 2) + check_int<std::int32_t>(n, 3) + check_int<std::int64_t>(n, 4);
+        bad += check_float<float, std::uint32_t>(n, 5) + check_float<double, std::uint64_t>(n, 6);
+    }
+    // a CPU tuner cannot be honoured here: throws, data untouched
+    std::vector<std::uint32_t> keep = {9, 8, 7, 6};
+    try { rdst::radix_sort_builder(keep).with_low_mem_tuner().sort(); ++bad; } catch (const rdst::Error&) {}
+    bad += !(keep == std::vector<std::uint32_t>{9, 8, 7, 6});
+    rdst::tuner::GpuTuner gpu(2);
+    rdst::radix_sort_builder(keep).with_tuner(&gpu).sort();
+    bad += !(keep == std::vector<std::uint32_t>{6, 7, 8, 9});
+    std::printf("%s (%d failed checks)\n", bad ? "FAIL" : "ok", bad);
+    return bad ? 1 : 0;
+}
