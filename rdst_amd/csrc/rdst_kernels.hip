@@ -256,10 +256,83 @@ __device__ __forceinline__ uint32_t digit_word(K mapped, int shift) {  // 32-bit
     else return (uint32_t)mapped;
 }
 
+// Decoupled look-back: thread d walks digit d's status words of rows t-1, t-2, ... and returns in
+// `excl` the sum up to and including the first INCLUSIVE one.  The walk is the latency chain of
+// the whole pass (each round trip crosses the fabric), so RDST_LB_WINDOW predecessor words are
+// fetched at once and then consumed in order.  Bounded: returns false if a word stays EMPTY.
+template <typename S>
+__device__ __forceinline__ bool lookback_walk(const S* __restrict__ status, uint32_t t, int tid, const uint32_t* err,
+                                              uint64_t& excl
+#ifdef RDST_EXPERIMENTS
+                                              , int level
+#endif
+) {
+    constexpr int SSHIFT = StatusWord<S>::SHIFT;
+    constexpr S SMASK = StatusWord<S>::MASK;
+    constexpr int LB_WINDOW = RDST_LB_WINDOW;
+    int64_t prev = (int64_t)t - 1;  // next row whose word is still to be consumed
+    uint32_t spins = 0;
+    bool done = false;
+#ifdef RDST_EXPERIMENTS
+    const uint64_t lb_t0 = __builtin_amdgcn_s_memtime();
+    uint32_t lb_iters = 0;
+#endif
+    while (!done) {
+#ifdef RDST_EXPERIMENTS
+        ++lb_iters;
+#endif
+        S v[LB_WINDOW];
+#pragma unroll
+        for (int k = 0; k < LB_WINDOW; ++k) {
+            const int64_t idx = prev - k;
+            // row 0 is always INCLUSIVE, so an index below 0 is never consumed
+            v[k] = idx >= 0 ? ld_relaxed<S>(status + (size_t)idx * RADIX + tid) : ((S)ST_INCL << SSHIFT);
+        }
+        bool blocked = false;
+        int consumed = 0;
+#pragma unroll
+        for (int k = 0; k < LB_WINDOW; ++k) {
+            const uint32_t st = (uint32_t)(v[k] >> SSHIFT);
+            if (!done && !blocked) {
+                if (st == ST_EMPTY) {
+                    blocked = true;
+                } else {
+                    excl += (uint64_t)(v[k] & SMASK);
+                    ++consumed;
+                    done = st == ST_INCL;
+                }
+            }
+        }
+        prev -= consumed;
+        if (blocked && !done) {
+            __builtin_amdgcn_s_sleep(2);
+            ++spins;
+            if (spins > SPIN_LIMIT || ((spins & 255u) == 0 && ld_relaxed<uint32_t>(err) != 0)) return false;
+        }
+    }
+#ifdef RDST_EXPERIMENTS
+    if (tid == 0 && g_exp_stats && level == 0) {  // digit 0's walker, one record per row, no atomics
+        uint32_t* rec = g_exp_stats + (size_t)t * 4;
+        rec[0] = lb_iters;
+        rec[1] = spins;
+        rec[2] = (uint32_t)((int64_t)t - 1 - prev);
+        rec[3] = (uint32_t)(__builtin_amdgcn_s_memtime() - lb_t0);
+    }
+#endif
+    return true;
+}
+
 // registers are capped so that the LDS-limited number of blocks per CU (3 at 32 KiB of staging,
 // more below) is not cut further by VGPRs: second launch-bound argument = waves per SIMD
+constexpr int blocks_per_cu(int nwaves, int stage_bytes) {
+    const int lds = nwaves * 1024 + 2048 + 64 + stage_bytes;
+    int b = 160 * 1024 / lds;
+    if (b * nwaves > 32) b = 32 / nwaves;
+    if (b > 3) b = 3;  // beyond three the register budget (<= 64) costs more than it buys
+    return b < 1 ? 1 : b;
+}
 template <typename K, typename S, int KPT, int NWAVES, int STAGES, bool MAPPED, bool NARROW>
-__global__ __launch_bounds__(NWAVES * 64, (NWAVES * 64 * KPT * (int)sizeof(K) / STAGES > 32768 ? 2 : 3) * NWAVES / 4) void onesweep_kernel(
+__global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NWAVES * 64 * KPT * (int)sizeof(K) / STAGES) * NWAVES + 3) / 4) void onesweep_kernel(
     K* __restrict__ buf_keys, K* __restrict__ buf_tmp, uint64_t n, int level,
     const uint64_t* __restrict__ base /* [256] of this level */, S* __restrict__ status /* [tiles][256] of this level */,
     uint32_t* __restrict__ ticket /* of this level */, const Plan* __restrict__ plan, uint32_t* __restrict__ err,
@@ -410,67 +483,17 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES * 64 * KPT * (int)sizeof(K) / 
         }
     }
 
-    // 7. decoupled look-back over the earlier tiles (thread d walks digit d).  The walk is the
-    //    latency chain of the whole pass (each round trip crosses the fabric), so LB_WINDOW
-    //    predecessor words are fetched at once and then consumed in order.
+    // 7. decoupled look-back over the earlier tiles (thread d walks digit d)
     if (tid < RADIX) {
         uint64_t excl = 0;
         bool fail = false;
         if (t > 0 && !RDST_ABL(0)) {
-            constexpr int LB_WINDOW = RDST_LB_WINDOW;
-            int64_t prev = (int64_t)t - 1;  // next tile whose word is still to be consumed
-            uint32_t spins = 0;
-            bool done = false;
+            fail = !lookback_walk<S>(status, t, tid, err, excl
 #ifdef RDST_EXPERIMENTS
-            const uint64_t lb_t0 = __builtin_amdgcn_s_memtime();
-            uint32_t lb_iters = 0;
+                                     , level
 #endif
-            while (!done) {
-#ifdef RDST_EXPERIMENTS
-                ++lb_iters;
-#endif
-                S v[LB_WINDOW];
-#pragma unroll
-                for (int k = 0; k < LB_WINDOW; ++k) {
-                    const int64_t idx = prev - k;
-                    // tile 0 is always INCL, so an index below 0 is never consumed
-                    v[k] = idx >= 0 ? ld_relaxed<S>(status + (size_t)idx * RADIX + tid) : ((S)ST_INCL << SSHIFT);
-                }
-                bool blocked = false;
-                int consumed = 0;
-#pragma unroll
-                for (int k = 0; k < LB_WINDOW; ++k) {
-                    const uint32_t st = (uint32_t)(v[k] >> SSHIFT);
-                    if (!done && !blocked) {
-                        if (st == ST_EMPTY) {
-                            blocked = true;
-                        } else {
-                            excl += (uint64_t)(v[k] & SMASK);
-                            ++consumed;
-                            done = st == ST_INCL;
-                        }
-                    }
-                }
-                prev -= consumed;
-                if (blocked && !done) {
-                    __builtin_amdgcn_s_sleep(2);
-                    ++spins;
-                    if (spins > SPIN_LIMIT || ((spins & 255u) == 0 && ld_relaxed<uint32_t>(err) != 0)) {
-                        fail = true;
-                        break;
-                    }
-                }
-            }
+            );
             if (!fail) st_relaxed<S>(&row[tid], ((S)ST_INCL << SSHIFT) | ((S)(excl + pub) & SMASK));
-#ifdef RDST_EXPERIMENTS
-            if (tid == 0 && g_exp_stats && level == 0) {  // digit 0's walker, one record per tile, no atomics
-                uint32_t* rec = g_exp_stats + (size_t)t * 4;
-                rec[0] = lb_iters;
-                rec[1] = spins;
-                rec[2] = (uint32_t)((int64_t)t - 1 - prev);
-                rec[3] = (uint32_t)(__builtin_amdgcn_s_memtime() - lb_t0);
-            }
-#endif
         }
         if (fail) {
             atomicOr(err, ERR_LOOKBACK_TIMEOUT);
@@ -595,17 +618,19 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
     } while (0)
 
 struct PassCfg { int nwaves, kpt4, kpt8, stages; };
+// Scatter-kernel shapes.  The pass is bound by the look-back walk, whose cost per tile is set
+// by latency, so throughput grows with the keys a resident block holds: the
+// defaults are the largest tiles that neither spill registers nor cost a block per CU.
 constexpr PassCfg kPassCfgs[] = {
-    {8, 16, 8, 1},    // 0: 512 threads,  8192 / 4096 keys per tile, whole tile staged (32 KiB)
-    {8, 32, 16, 2},   // 1: 512 threads, 16384 / 8192 keys per tile, staged in two halves (32 KiB)
-    {8, 24, 12, 2},   // 2: 512 threads, 12288 / 6144 keys per tile, two halves (24 KiB)
-    {8, 24, 12, 1},   // 3: 512 threads, 12288 / 6144 keys per tile, whole tile staged (48 KiB)
-    {8, 16, 8, 2},    // 4: 512 threads,  8192 / 4096 keys per tile, two halves (16 KiB)
-    {4, 32, 16, 2},   // 5: 256 threads,  8192 / 4096 keys per tile, two halves (16 KiB)
+    {8, 16, 8, 1},    // 0: 512 threads,  8192 / 4096 keys per tile, whole tile staged in LDS (32 KiB)
+    {8, 24, 12, 2},   // 1: 512 threads, 12288 / 6144 keys per tile, staged in two halves (24 KiB)
+    {12, 24, 12, 2},  // 2: 768 threads, 18432 / 9216 keys per tile, two halves (36 KiB)   <- default, 4-byte keys
+    {12, 28, 14, 2},  // 3: 768 threads, 21504 / 10752 keys per tile, two halves (42 KiB)  <- default, 8-byte keys
 };
 constexpr int kNumPassCfgs = sizeof(kPassCfgs) / sizeof(kPassCfgs[0]);
+constexpr int default_cfg(uint32_t elem_bytes) { return elem_bytes == 8 ? 3 : 2; }
 
-struct Tuning { int pass_cfg = 2; int hist_bpc = 0; bool profiling = false; };
+struct Tuning { int pass_cfg = -1; int hist_bpc = 0; bool profiling = false; };  // pass_cfg < 0: default_cfg()
 uint32_t g_ablate = 0;  // only ever set by the RDST_EXPERIMENTS build
 #ifdef RDST_EXPERIMENTS
 size_t g_exp_lds_total = 0;
@@ -794,11 +819,9 @@ int launch_pass_s(int cfg, K* keys, K* tmp, uint64_t n, int level, const Layout&
     constexpr int F = sizeof(K) == 4 ? 2 : 1;  // 4-byte keys: twice the keys per thread, same bytes
     switch (cfg) {
         case 0: return launch_pass_t<K, S, 8 * F, 8, 1, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, s);
-        case 1: return launch_pass_t<K, S, 16 * F, 8, 2, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, s);
-        case 2: return launch_pass_t<K, S, 12 * F, 8, 2, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, s);
-        case 3: return launch_pass_t<K, S, 12 * F, 8, 1, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, s);
-        case 4: return launch_pass_t<K, S, 8 * F, 8, 2, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, s);
-        case 5: return launch_pass_t<K, S, 16 * F, 4, 2, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, s);
+        case 1: return launch_pass_t<K, S, 12 * F, 8, 2, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, s);
+        case 2: return launch_pass_t<K, S, 12 * F, 12, 2, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, s);
+        case 3: return launch_pass_t<K, S, 14 * F, 12, 2, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, s);
     }
     return fail(RDST_ERR_ARG, "bad pass config");
 }
@@ -829,7 +852,7 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     int rc = current_device_state(&D);
     if (rc) return rc;
     int cfg = g_tuning.pass_cfg;
-    if (cfg < 0 || cfg >= kNumPassCfgs) cfg = 2;
+    if (cfg < 0 || cfg >= kNumPassCfgs) cfg = default_cfg(sizeof(K));
     const Layout L = make_layout(n, sizeof(K), LEVELS, cfg);
     if (L.tiles >= (1ull << 31)) return fail(RDST_ERR_ARG, "len too large for one launch");
     rc = ensure_workspace(*D, L.total);
@@ -924,7 +947,7 @@ int rdst_hip_abi_version(void) { return RDST_HIP_ABI_VERSION; }
 int rdst_hip_set_tuning(int pass_config, int hist_blocks_per_cu) {
     std::lock_guard<std::mutex> lock(g_mutex);
     if (pass_config >= kNumPassCfgs) return fail(RDST_ERR_ARG, "tuning value out of range");
-    g_tuning.pass_cfg = pass_config >= 0 ? pass_config : 2;
+    g_tuning.pass_cfg = pass_config >= 0 ? pass_config : -1;
     g_tuning.hist_bpc = hist_blocks_per_cu > 0 ? hist_blocks_per_cu : 0;
     return RDST_OK;
 }
@@ -989,6 +1012,7 @@ int rdst_hip_profile_run(int run, float* out_ms, uint32_t capacity, uint32_t* n_
 uint64_t rdst_hip_workspace_bytes(uint64_t len, uint32_t elem_bytes) {
     if (elem_bytes != 4 && elem_bytes != 8) return 0;
     int cfg = g_tuning.pass_cfg;
+    if (cfg < 0 || cfg >= kNumPassCfgs) cfg = default_cfg(elem_bytes);
     return make_layout(len, elem_bytes, elem_bytes, cfg).total;
 }
 

@@ -52,7 +52,7 @@ def test_host_entry_point_sorts_numpy_in_place(gpu, oracle):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_sort_matches_oracle_over_sizes(gpu, oracle, dtype):
-    tile = 8192 if np.dtype(dtype).itemsize == 4 else 4096
+    tile = 18432 if np.dtype(dtype).itemsize == 4 else 10752
     sizes = [0, 1, 2, 3, 10, 100, 127, 128, 129, 5_000, tile - 1, tile, tile + 1, 2 * tile - 1, 2 * tile + 1, 50_000,
              100_000, 300_000, 1_000_003, 5_000_011]
     for i, n in enumerate(sizes):

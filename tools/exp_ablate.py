@@ -24,13 +24,13 @@ def main():
         e0.record(); keys.copy_(src); e1.record(); torch.cuda.synchronize()
     print('device copy of the same array (4 GB read + 4 GB write): %.3f ms' % e0.elapsed_time(e1), flush=True)
     lds_list = [int(x) for x in os.environ.get("RDST_EXP_LDS", "0").split(",")]
-    for cfg, lds_total in [(c, l) for c in [int(x) for x in os.environ.get("RDST_EXP_CFGS", "0,1,2,3,4,5").split(",")] for l in lds_list]:
+    for cfg, lds_total in [(c, l) for c in [int(x) for x in os.environ.get("RDST_EXP_CFGS", "0,1,2,3").split(",")] for l in lds_list]:
         rdst_amd.set_tuning(cfg, 0)
         lib.rdst_hip_exp_set_lds(ctypes.c_uint32(lds_total))
         print(f"-- cfg {cfg} dynamic LDS forced to >= {lds_total} B", flush=True)
         for mask, name in names.items():
             lib.rdst_hip_exp_set_ablation(ctypes.c_uint32(mask))
-            tile = {0: 8192, 1: 16384, 2: 12288, 3: 12288, 4: 8192, 5: 8192}[cfg]
+            tile = {0: 8192, 1: 12288, 2: 18432, 3: 21504}[cfg]
             stats_tiles = (n + tile - 1) // tile if not (mask & 1) else 0
             if stats_tiles:
                 lib.rdst_hip_exp_stats(None, ctypes.c_uint64(stats_tiles))
