@@ -415,8 +415,29 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NWAVES * 64 * K
     uint32_t* wh = wave_hist + wave * RADIX;
 #pragma unroll
     for (int j = 0; j < 4; ++j) wh[lane + 64 * j] = 0;
+    // Sorted or low-entropy input puts all 64 lanes of a round on one bin, which would serialise
+    // the LDS atomic 64 ways: a wave-uniform round is counted (and later ranked) by one lane.
+    // Looking for such rounds costs a few instructions each, so it is only done when the wave's
+    // first round is one (random keys: never).
+    uint32_t uniform_rounds = 0;  // bit i: round i holds a single digit (wave-uniform value)
+    {
+        const uint32_t d0 = digit_of(mk[0], shift);
+        if (__all((int)(d0 == (uint32_t)__builtin_amdgcn_readfirstlane((int)d0))) != 0) {
 #pragma unroll
-    for (int i = 0; i < KPT; ++i) atomicAdd(&wh[digit_of(mk[i], shift)], 1u);
+            for (int i = 0; i < KPT; ++i) {
+                const uint32_t d = digit_of(mk[i], shift);
+                if (__all((int)(d == (uint32_t)__builtin_amdgcn_readfirstlane((int)d))) != 0) {
+                    if (lane == 0) wh[d] += 64u;
+                    uniform_rounds |= 1u << i;
+                } else {
+                    atomicAdd(&wh[d], 1u);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) atomicAdd(&wh[digit_of(mk[i], shift)], 1u);
+        }
+    }
     __syncthreads();
 
     // 3. thread d: digit count over the block's waves; publish the tile aggregate at once
@@ -467,9 +488,16 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NWAVES * 64 * K
     for (int i = 0; i < KPT; ++i) {
         uint32_t* slot = &wh[digit_of(mk[i], shift)];
         const uint32_t b = *slot;
-        const uint32_t below = RDST_ABL(3) ? 0u : peers_below(digit_word<K>(mk[i], shift), bit0);
-        __builtin_amdgcn_wave_barrier();
-        atomicAdd(slot, 1u);
+        uint32_t below;
+        if ((uniform_rounds >> i) & 1u) {  // wave-uniform branch
+            below = (uint32_t)lane;
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) *slot = b + 64u;
+        } else {
+            below = RDST_ABL(3) ? 0u : peers_below(digit_word<K>(mk[i], shift), bit0);
+            __builtin_amdgcn_wave_barrier();
+            atomicAdd(slot, 1u);
+        }
         if constexpr (STAGES == 1) {
             s_keys[b + below] = mk[i];
         } else {

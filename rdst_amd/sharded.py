@@ -82,8 +82,12 @@ def sharded_sort(local_keys, group=None, engine=None, return_info: bool = False)
         return (out, {"owner": [0] * 256, "recv": [out.numel()]}) if return_info else out
 
     dev = local_keys.device
+    # RCCL ("nccl") moves device tensors directly.  Under gloo (CPU tests, or several test ranks
+    # sharing one GPU) device tensors are staged through the host for the two collectives.
+    via_host = local_keys.is_cuda and dist.get_backend(group) == "gloo"
+    cdev = torch.device("cpu") if via_host else dev
     # 1-2. local histogram, all-gather (2 KiB per rank)
-    mine = torch.from_numpy(engine.top_level_counts(local_keys)).to(dev)
+    mine = torch.from_numpy(engine.top_level_counts(local_keys)).to(cdev)
     gathered = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(gathered, mine, group=group)
     table = torch.stack(gathered).cpu().numpy()  # [rank][digit]
@@ -97,8 +101,14 @@ def sharded_sort(local_keys, group=None, engine=None, return_info: bool = False)
     # 5. exchange
     inbox = engine.empty(sum(recv), local_keys)
     as_int = {4: torch.int32, 8: torch.int64}[local_keys.element_size()]
-    dist.all_to_all_single(inbox.view(as_int), grouped.view(as_int), output_split_sizes=recv,
-                           input_split_sizes=send, group=group)
+    if via_host:
+        host_in = torch.empty(sum(recv), dtype=as_int)
+        dist.all_to_all_single(host_in, grouped.view(as_int).cpu(), output_split_sizes=recv, input_split_sizes=send,
+                               group=group)
+        inbox.view(as_int).copy_(host_in)
+    else:
+        dist.all_to_all_single(inbox.view(as_int), grouped.view(as_int), output_split_sizes=recv,
+                               input_split_sizes=send, group=group)
     del grouped
     # 6. local LSD over every level (arrivals are only range-partitioned)
     engine.sort(inbox)

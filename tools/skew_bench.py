@@ -1,0 +1,40 @@
+"""Development aid: device sort time on non-uniform inputs (1e9 u32 keys unless argv[1])."""
+import sys
+import torch
+sys.path.insert(0, ".")
+import rdst_amd
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000_000
+g = torch.Generator(device="cuda").manual_seed(5)
+rnd = torch.randint(-(2**31), 2**31, (n,), dtype=torch.int32, device="cuda", generator=g)
+cases = {
+    "uniform random": rnd,
+    "already sorted (arange)": torch.arange(n, dtype=torch.int32, device="cuda"),
+    "reverse sorted": torch.arange(n - 1, -1, -1, dtype=torch.int32, device="cuda"),
+    "sorted random": None,
+    "16-bit values (two empty levels)": rnd & 0xFFFF,
+    "bimodal (gen_inputs shift 16)": torch.cat([(rnd[: n // 2] >> 16) & 0xFFFF, rnd[n // 2:] << 16]),
+    "all equal": torch.full((n,), 1234567, dtype=torch.int32, device="cuda"),
+    "256 distinct values": rnd & 0xFF00,
+}
+tmp = torch.empty(n, dtype=torch.uint32, device="cuda")
+keys = torch.empty(n, dtype=torch.int32, device="cuda")
+for name, src in cases.items():
+    if src is None:
+        src = rnd.clone().view(torch.uint32)
+        rdst_amd.sort_device_tensor(src, tmp)
+        src = src.view(torch.int32)
+    times = []
+    for _ in range(3):
+        keys.copy_(src)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rdst_amd.sort_device_tensor(keys.view(torch.uint32), tmp, check=False)
+        e1.record()
+        torch.cuda.synchronize()
+        rdst_amd.device_status()
+        times.append(e0.elapsed_time(e1))
+    k = keys ^ (-(2**31))
+    ok = bool((k[1:] >= k[:-1]).all()) and int(keys.sum()) == int(src.sum())
+    print(f"{name:36s}: {min(times):8.3f} ms  {n / min(times) / 1e6:7.1f} Gkeys/s  ok={ok}", flush=True)
