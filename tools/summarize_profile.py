@@ -41,6 +41,24 @@ if "FETCH_SIZE" in one and "WRITE_SIZE" in one:
         t["hist_fetch_bytes_per_launch"] = out["hist_kernel"]["FETCH_SIZE"]["mean_per_launch"] * 1024 * 2
     json.dump(t, open("profiles/pmc_traffic.json", "w"), indent=1)
     print(json.dumps(t, indent=1))
+traces = glob.glob(f"{src}/trace/*/*_kernel_trace.csv")
+if traces:
+    # per-launch durations of the scatter pass in the traced bench run (--steps 3 --warmup 1: the first
+    # 4 launches belong to the untimed warm-up step and run slower; kernel_stats.csv averages them in)
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in csv.DictReader(open(traces[0]))
+         if "onesweep" in r["Kernel_Name"]]
+    h = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in csv.DictReader(open(traces[0]))
+         if "hist_kernel" in r["Kernel_Name"]]
+    bench_line = None
+    for line in open(f"{src}/trace.log"):
+        if line.startswith("{") and "roofline" in line:
+            bench_line = json.loads(line)
+    summ = {"onesweep_launch_ms": [round(x, 4) for x in d], "onesweep_avg_ms_all_launches": sum(d) / len(d),
+            "onesweep_avg_ms_timed_steps": sum(d[4:]) / max(1, len(d[4:])), "hist_launch_ms": [round(x, 4) for x in h],
+            "bench_line_of_the_same_run": bench_line}
+    json.dump(summ, open(f"profiles/{tag}_kernel_trace_summary.json", "w"), indent=1)
+    print("onesweep avg (timed steps) %.4f ms, bench events in the same run: %s" % (
+        summ["onesweep_avg_ms_timed_steps"], bench_line and bench_line["roofline"]["avg_launch_ms"]))
 if stats:
     for row in list(csv.DictReader(open(stats[0])))[:6]:
         print(row["Name"][:70], row["Calls"], row["AverageNs"], row["Percentage"])
