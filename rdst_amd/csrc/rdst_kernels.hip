@@ -94,6 +94,19 @@ __device__ __forceinline__ void st_relaxed(S* p, S v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// value held by lane - 1 (lane 0: unspecified), as a DPP wave shift: no LDS traffic
+template <typename K>
+__device__ __forceinline__ K lane_below(K x) {
+    constexpr int WAVE_SHR1 = 0x138;
+    if constexpr (sizeof(K) == 4) {
+        return (K)__builtin_amdgcn_mov_dpp((int)x, WAVE_SHR1, 0xf, 0xf, false);
+    } else {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)x, WAVE_SHR1, 0xf, 0xf, false);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(x >> 32), WAVE_SHR1, 0xf, 0xf, false);
+        return (K)lo | ((K)hi << 32);
+    }
+}
+
 // lanes of this wave holding the same 8-bit digit (all 64 lanes must be active)
 __device__ __forceinline__ uint64_t match_any8(uint32_t d) {
     uint64_t m = ~0ull;
@@ -126,7 +139,8 @@ constexpr int HIST_THREADS = 1024;
 
 template <typename K, int LEVELS, int VEC>
 __global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const K* __restrict__ keys, uint64_t n, K neg, K pos,
-                                                            unsigned long long* __restrict__ hist) {
+                                                            unsigned long long* __restrict__ hist,
+                                                            uint32_t* __restrict__ inversion /* set if keys[i-1] > keys[i] anywhere */) {
     constexpr int COPIES = LEVELS <= 4 ? 32 : 16;
     constexpr int WORDS = LEVELS * RADIX * COPIES;  // 32768 words = 128 KiB
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -143,11 +157,24 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const K* __restrict_
     if (p_end > n) p_end = n;
     uint32_t* mine = s_h + (tid & (COPIES - 1));  // my bank column
 
-    auto count = [&](K raw) {
+    // Besides counting, the sweep looks for an inversion in mapped-key order: a slice that is
+    // already sorted needs no pass at all (the whole-slice form of rdst's already_sorted exits,
+    // src/sorter.rs:59-65, src/sort_utils.rs:125-136).  `before` = mapped key at the previous index.
+#ifndef RDST_NO_SORTED_CHECK
+    bool inv = false;
+#else
+    bool inv = true;  // A/B build without the test: never claim "sorted"
+#endif
+    auto count = [&](K raw, K before) -> K {
         const K m = map_key<K>(raw, neg, pos);
+#ifndef RDST_NO_SORTED_CHECK
+        inv |= before > m;
+#endif
 #pragma unroll
         for (int l = 0; l < LEVELS; ++l) atomicAdd(&mine[(l * RADIX + digit_of(m, l * 8)) * COPIES], 1u);
+        return m;
     };
+    auto mapped_at = [&](uint64_t idx) -> K { return idx == 0 ? (K)0 : map_key<K>(keys[idx - 1], neg, pos); };  // key before idx
 
     struct alignas(sizeof(K) * VEC) V { K e[VEC]; };
     uint64_t i = p_begin + (uint64_t)tid * VEC;
@@ -156,16 +183,32 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const K* __restrict_
         V v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const V*>(keys + i + u * STRIDE);
+#ifndef RDST_NO_SORTED_CHECK
+        // key before my vector = last key of the lane below (its vector ends where mine begins);
+        // only lane 0 of a wave has to fetch it, in the same batch as the vectors
+        K edge[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < 4; ++u) edge[u] = ((tid & 63) == 0 && i + u * STRIDE > 0) ? keys[i + u * STRIDE - 1] : (K)0;
+#endif
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) count(v[u].e[e]);
+        for (int u = 0; u < 4; ++u) {
+#ifndef RDST_NO_SORTED_CHECK
+            K before = lane_below<K>(map_key<K>(v[u].e[VEC - 1], neg, pos));
+            if ((tid & 63) == 0) before = (i + u * STRIDE > 0) ? map_key<K>(edge[u], neg, pos) : (K)0;
+#else
+            K before = 0;
+#endif
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) before = count(v[u].e[e], before);
+        }
     }
     for (; i < p_end; i += STRIDE) {  // remainder of the piece, element-wise
+        K before = mapped_at(i);
 #pragma unroll
         for (int e = 0; e < VEC; ++e)
-            if (i + e < p_end) count(keys[i + e]);
+            if (i + e < p_end) before = count(keys[i + e], before);
     }
+    if (inv) atomicOr(inversion, 1u);
     __syncthreads();
     // fold the copies: thread j owns (level, digit) pair j (+1024, ...); reading copy (c + j) % COPIES
     // in step c keeps the lanes of a half-wave on distinct banks
@@ -184,7 +227,7 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const K* __restrict_
 __global__ __launch_bounds__(256) void scan_kernel(const unsigned long long* __restrict__ hist,
                                                    uint64_t* __restrict__ base, Plan* plan, uint32_t levels,
                                                    uint64_t n, uint32_t allow_skip, uint32_t level_lo,
-                                                   uint32_t level_hi) {
+                                                   uint32_t level_hi, const uint32_t* __restrict__ inversion) {
     __shared__ uint64_t s_scan[RADIX];
     __shared__ uint32_t s_trivial[MAX_LEVELS];
     const int d = threadIdx.x;
@@ -207,9 +250,10 @@ __global__ __launch_bounds__(256) void scan_kernel(const unsigned long long* __r
     }
     if (d == 0) {
         uint32_t in_tmp = 0, executed = 0;
+        const bool already_sorted = allow_skip && *inversion == 0;  // nothing to do at all
         for (uint32_t l = 0; l < MAX_LEVELS; ++l) {
             const bool active = l >= level_lo && l < level_hi && l < levels;
-            const bool skip = !active || (allow_skip && s_trivial[l]);
+            const bool skip = !active || already_sorted || (allow_skip && s_trivial[l]);
             plan->skip[l] = skip ? 1u : 0u;
             plan->src_is_tmp[l] = in_tmp;
             if (!skip) { in_tmp ^= 1u; ++executed; }
@@ -790,7 +834,8 @@ KeyMap key_map_for(rdst_key_kind kind, uint32_t elem_bytes) {
 }
 
 template <typename K, int LEVELS, int VEC>
-int launch_hist_v(const K* keys, uint64_t n, uint32_t blocks, KeyMap km, unsigned long long* hist, hipStream_t s) {
+int launch_hist_v(const K* keys, uint64_t n, uint32_t blocks, KeyMap km, unsigned long long* hist, uint32_t* inversion,
+                  hipStream_t s) {
     constexpr size_t lds = (size_t)LEVELS * RADIX * (LEVELS <= 4 ? 32 : 16) * sizeof(uint32_t);
     static bool attr_set = false;
     if (!attr_set) {
@@ -799,16 +844,17 @@ int launch_hist_v(const K* keys, uint64_t n, uint32_t blocks, KeyMap km, unsigne
         attr_set = true;
     }
     hipLaunchKernelGGL((hist_kernel<K, LEVELS, VEC>), dim3(blocks), dim3(HIST_THREADS), lds, s, keys, n, (K)km.neg,
-                       (K)km.pos, hist);
+                       (K)km.pos, hist, inversion);
     HIP_TRY(hipGetLastError());
     return RDST_OK;
 }
 
 template <typename K, int LEVELS>
-int launch_hist(const K* keys, uint64_t n, uint32_t blocks, KeyMap km, unsigned long long* hist, hipStream_t s) {
+int launch_hist(const K* keys, uint64_t n, uint32_t blocks, KeyMap km, unsigned long long* hist, uint32_t* inversion,
+                hipStream_t s) {
     const bool aligned = (reinterpret_cast<uintptr_t>(keys) & 15u) == 0;
-    if (aligned) return launch_hist_v<K, LEVELS, 16 / sizeof(K)>(keys, n, blocks, km, hist, s);
-    return launch_hist_v<K, LEVELS, 1>(keys, n, blocks, km, hist, s);
+    if (aligned) return launch_hist_v<K, LEVELS, 16 / sizeof(K)>(keys, n, blocks, km, hist, inversion, s);
+    return launch_hist_v<K, LEVELS, 1>(keys, n, blocks, km, hist, inversion, s);
 }
 
 template <typename K, typename S, int KPT, int NWAVES, int STAGES, bool MAPPED, bool NARROW>
@@ -906,12 +952,13 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     if (blocks > max_useful) blocks = max_useful;
     if (blocks < 1) blocks = 1;
     unsigned long long* hist = reinterpret_cast<unsigned long long*>(ws + L.off_hist);
-    rc = launch_hist<K, LEVELS>(keys, n, (uint32_t)blocks, km, hist, s);
+    uint32_t* inversion = reinterpret_cast<uint32_t*>(ws + L.off_err) + 1;  // second word of the (cleared) header
+    rc = launch_hist<K, LEVELS>(keys, n, (uint32_t)blocks, km, hist, inversion, s);
     if (rc) return rc;
     if ((rc = prof_mark(*D, s))) return rc;
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(256), 0, s, hist, reinterpret_cast<uint64_t*>(ws + L.off_base),
                        reinterpret_cast<Plan*>(ws + L.off_plan), (uint32_t)LEVELS, n, allow_skip ? 1u : 0u, level_lo,
-                       level_hi);
+                       level_hi, inversion);
     HIP_TRY(hipGetLastError());
     if ((rc = prof_mark(*D, s))) return rc;
     for (uint32_t level = level_lo; level < level_hi; ++level) {

@@ -90,6 +90,28 @@ def test_degenerate_orders(gpu, dtype):
         assert np.array_equal(_device_sort(gpu, a), np.sort(a)), name
 
 
+@pytest.mark.parametrize("dtype", ["uint32", "uint64", "float32"])
+def test_already_sorted_detection_sees_every_adjacent_pair(gpu, dtype):
+    """The histogram sweep skips every pass when it finds no inversion (the whole-slice form of
+    rdst's already_sorted exits, src/sorter.rs:59-65).  One swapped neighbour pair anywhere —
+    inside a 16-byte vector, across lanes, waves, sweeps, block pieces, at either end — must
+    still be found."""
+    n = 5_000_003
+    base = reference_sorted(random_bits(n, dtype, seed=77))
+    assert same_bits(_device_sort(gpu, base), base)          # sorted stays sorted
+    vec = 16 // np.dtype(dtype).itemsize
+    piece = -(-n // 256)                                      # ~ one block's share of the sweep
+    spots = [0, 1, vec - 1, vec, 64 * vec - 1, 64 * vec, 1024 * vec - 1, 1024 * vec, 4 * 1024 * vec - 1, 4 * 1024 * vec,
+             piece - 1, piece, piece + 1, 2 * piece, n // 2, n - 3, n - 2]
+    k = mapped_key(base)
+    for i in spots:
+        if k[i] == k[i + 1]:
+            continue
+        a = base.copy()
+        a[i], a[i + 1] = base[i + 1], base[i]
+        assert same_bits(_device_sort(gpu, a), base), (dtype, i)
+
+
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
 def test_float_specials(gpu, oracle, dtype):
     sp = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, -np.nan, 1.0, -1.0, 5e-324, -5e-324, 1e30, -1e30], dtype=dtype)
