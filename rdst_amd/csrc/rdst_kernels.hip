@@ -594,32 +594,37 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NWAVES * 64 * K
             }
             __syncthreads();
         }
-        K kk[SPT];
-        D dd[SPT];
+        // slots of this stage in sub-batches (fewer live registers than one batch of SPT)
+        constexpr int SUB = SPT % 6 == 0 ? 6 : (SPT % 4 == 0 ? 4 : SPT);
 #pragma unroll
-        for (int i = 0; i < SPT; ++i) kk[i] = s_keys[tid + i * BLOCK];
+        for (int i0 = 0; i0 < SPT; i0 += SUB) {
+            K kk[SUB];
+            D dd[SUB];
 #pragma unroll
-        for (int i = 0; i < SPT; ++i) dd[i] = s_delta[digit_of(kk[i], shift)];
+            for (int i = 0; i < SUB; ++i) kk[i] = s_keys[tid + (i0 + i) * BLOCK];
 #pragma unroll
-        for (int i = 0; i < SPT; ++i) {
-            const uint32_t p = (uint32_t)(stage * STAGE_KEYS) + (uint32_t)tid + (uint32_t)i * BLOCK;  // slot in the tile
-            K out = kk[i];
-            if constexpr (MAPPED) out = unmap_key<K>(out, neg, pos);
-            if (RDST_ABL(1) && out != (K)0x12345) continue;  // no stores
-            if (RDST_ABL(2)) {                                // sequential stores instead of the scatter
-                if (full || p < valid) dst[tile_begin + p] = out;
-                continue;
-            }
-            if constexpr (NARROW) {
-                const uint32_t g = dd[i] + p * (uint32_t)sizeof(K);  // byte offset, < 2^32
-                const bool ok = g < (uint32_t)n * (uint32_t)sizeof(K);
-                bad |= !ok && (full || p < valid);
-                if (ok && (full || p < valid)) *reinterpret_cast<K*>(reinterpret_cast<unsigned char*>(dst) + g) = out;
-            } else {
-                const uint64_t g = dd[i] + p;
-                const bool ok = g < n;
-                bad |= !ok && (full || p < valid);
-                if (ok && (full || p < valid)) dst[g] = out;
+            for (int i = 0; i < SUB; ++i) dd[i] = s_delta[digit_of(kk[i], shift)];
+#pragma unroll
+            for (int i = 0; i < SUB; ++i) {
+                const uint32_t p = (uint32_t)(stage * STAGE_KEYS) + (uint32_t)tid + (uint32_t)(i0 + i) * BLOCK;  // slot in the tile
+                K out = kk[i];
+                if constexpr (MAPPED) out = unmap_key<K>(out, neg, pos);
+                if (RDST_ABL(1) && out != (K)0x12345) continue;  // no stores
+                if (RDST_ABL(2)) {                                // sequential stores instead of the scatter
+                    if (full || p < valid) dst[tile_begin + p] = out;
+                    continue;
+                }
+                if constexpr (NARROW) {
+                    const uint32_t g = dd[i] + p * (uint32_t)sizeof(K);  // byte offset, < 2^32
+                    const bool ok = g < (uint32_t)n * (uint32_t)sizeof(K);
+                    bad |= !ok && (full || p < valid);
+                    if (ok && (full || p < valid)) *reinterpret_cast<K*>(reinterpret_cast<unsigned char*>(dst) + g) = out;
+                } else {
+                    const uint64_t g = dd[i] + p;
+                    const bool ok = g < n;
+                    bad |= !ok && (full || p < valid);
+                    if (ok && (full || p < valid)) dst[g] = out;
+                }
             }
         }
     }
