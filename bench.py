@@ -95,11 +95,19 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be started with torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    # rehearsal knobs (not used by the driver): several ranks on ONE GPU with gloo collectives, to
+    # exercise the N > 1 code path on a single-GPU box (RCCL refuses two ranks on one device)
+    backend = os.environ.get("RDST_BENCH_BACKEND", "nccl")
+    if os.environ.get("RDST_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     distributed = world > 1
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import rdst_amd
     from rdst_amd.sharded import sharded_sort
@@ -146,7 +154,7 @@ def main():
     rdst_amd.set_profiling(False)
 
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
