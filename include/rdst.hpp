@@ -35,7 +35,7 @@ struct Error : std::runtime_error {
 // RadixKey (src/radix_key.rs:1-5) for the built-in types whose mapping the device knows.
 template <typename T, typename = void> struct RadixKey;  // not defined: no device mapping for T
 template <typename T>
-struct RadixKey<T, std::enable_if_t<std::is_integral_v<T> && !std::is_same_v<T, bool> && (sizeof(T) == 4 || sizeof(T) == 8)>> {
+struct RadixKey<T, std::enable_if_t<std::is_integral_v<T> && !std::is_same_v<T, bool> && sizeof(T) <= 8>> {
     static constexpr std::size_t LEVELS = sizeof(T);
     static constexpr rdst_key_kind kind = std::is_signed_v<T> ? RDST_KEY_SIGNED : RDST_KEY_UNSIGNED;
 };
@@ -125,12 +125,13 @@ class RadixSortBuilder {  // src/radix_sort_builder.rs:8-158
 
    private:
     static std::uint8_t top_digit(const T& v, int level) {  // RadixKey::get_level (src/radix_key_impl.rs)
-        using U = std::conditional_t<sizeof(T) == 4, std::uint32_t, std::uint64_t>;
+        using U = std::conditional_t<sizeof(T) == 1, std::uint8_t, std::conditional_t<sizeof(T) == 2, std::uint16_t,
+                  std::conditional_t<sizeof(T) == 4, std::uint32_t, std::uint64_t>>>;
         U u;
         __builtin_memcpy(&u, &v, sizeof u);
-        constexpr U msb = U(1) << (sizeof(U) * 8 - 1);
-        if (RadixKey<T>::kind == RDST_KEY_SIGNED) u ^= msb;
-        else if (RadixKey<T>::kind == RDST_KEY_FLOAT) u ^= (u & msb) ? ~U(0) : msb;
+        constexpr U msb = U(U(1) << (sizeof(U) * 8 - 1));
+        if (RadixKey<T>::kind == RDST_KEY_SIGNED) u = U(u ^ msb);
+        else if (RadixKey<T>::kind == RDST_KEY_FLOAT) u = U(u ^ ((u & msb) ? U(~U(0)) : msb));
         return static_cast<std::uint8_t>(u >> (level * 8));
     }
 };

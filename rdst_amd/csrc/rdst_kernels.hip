@@ -73,12 +73,12 @@ struct KeyMap {  // order-preserving map as two xor masks (src/radix_key_impl.rs
 template <typename K>
 __device__ __forceinline__ K map_key(K k, K neg, K pos) {
     constexpr int W = sizeof(K) * 8;
-    return k ^ ((k >> (W - 1)) ? neg : pos);
+    return (K)(k ^ ((K)(k >> (W - 1)) ? neg : pos));
 }
 template <typename K>
 __device__ __forceinline__ K unmap_key(K m, K neg, K pos) {
     constexpr int W = sizeof(K) * 8;
-    return m ^ ((m >> (W - 1)) ? pos : neg);
+    return (K)(m ^ ((K)(m >> (W - 1)) ? pos : neg));
 }
 template <typename K>
 __device__ __forceinline__ uint32_t digit_of(K mapped, int shift) {
@@ -98,7 +98,7 @@ __device__ __forceinline__ void st_relaxed(S* p, S v) {
 template <typename K>
 __device__ __forceinline__ K lane_below(K x) {
     constexpr int WAVE_SHR1 = 0x138;
-    if constexpr (sizeof(K) == 4) {
+    if constexpr (sizeof(K) <= 4) {
         return (K)__builtin_amdgcn_mov_dpp((int)x, WAVE_SHR1, 0xf, 0xf, false);
     } else {
         const uint32_t lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)x, WAVE_SHR1, 0xf, 0xf, false);
@@ -895,7 +895,7 @@ int launch_pass_t(K* keys, K* tmp, uint64_t n, int level, const Layout& L, char*
 
 template <typename K, typename S, bool MAPPED, bool NARROW>
 int launch_pass_s(int cfg, K* keys, K* tmp, uint64_t n, int level, const Layout& L, char* ws, KeyMap km, hipStream_t s) {
-    constexpr int F = sizeof(K) == 4 ? 2 : 1;  // 4-byte keys: twice the keys per thread, same bytes
+    constexpr int F = sizeof(K) <= 4 ? 2 : 1;  // keys of up to 4 bytes: twice the keys per thread
     switch (cfg) {
         case 0: return launch_pass_t<K, S, 8 * F, 8, 1, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, s);
         case 1: return launch_pass_t<K, S, 12 * F, 8, 2, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, s);
@@ -991,8 +991,19 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     return workspace_release(*D, s);
 }
 
+// run CALL with K = the unsigned integer type of `elem_bytes` bytes and LV = its RadixKey::LEVELS
+#define RDST_BY_WIDTH(elem_bytes, CALL)                                            \
+    switch (elem_bytes) {                                                          \
+        case 1: { using K = uint8_t; constexpr int LV = 1; CALL; } break;          \
+        case 2: { using K = uint16_t; constexpr int LV = 2; CALL; } break;         \
+        case 4: { using K = uint32_t; constexpr int LV = 4; CALL; } break;         \
+        default: { using K = uint64_t; constexpr int LV = 8; CALL; } break;        \
+    }
+
 int check_common(const void* p, uint64_t len, uint32_t elem_bytes, rdst_key_kind kind, uint32_t levels) {
-    if (elem_bytes != 4 && elem_bytes != 8) return fail(RDST_ERR_UNSUPPORTED, "device path is built for 4- and 8-byte keys");
+    if (elem_bytes != 1 && elem_bytes != 2 && elem_bytes != 4 && elem_bytes != 8)
+        return fail(RDST_ERR_UNSUPPORTED, "device path is built for 1-, 2-, 4- and 8-byte keys");
+    if (kind == RDST_KEY_FLOAT && elem_bytes < 4) return fail(RDST_ERR_UNSUPPORTED, "float keys are f32 / f64");
     if (levels == 0) return fail(RDST_ERR_ARG, "RadixKey must have at least 1 level");
     if (levels != elem_bytes) return fail(RDST_ERR_ARG, "levels must equal the element width for built-in key types");
     if ((int)kind < 0 || (int)kind > 2) return fail(RDST_ERR_ARG, "unknown key kind");
@@ -1090,7 +1101,7 @@ int rdst_hip_profile_run(int run, float* out_ms, uint32_t capacity, uint32_t* n_
 }
 
 uint64_t rdst_hip_workspace_bytes(uint64_t len, uint32_t elem_bytes) {
-    if (elem_bytes != 4 && elem_bytes != 8) return 0;
+    if (elem_bytes != 1 && elem_bytes != 2 && elem_bytes != 4 && elem_bytes != 8) return 0;
     int cfg = g_tuning.pass_cfg;
     if (cfg < 0 || cfg >= kNumPassCfgs) cfg = default_cfg(elem_bytes);
     return make_layout(len, elem_bytes, elem_bytes, cfg).total;
@@ -1105,9 +1116,8 @@ int rdst_hip_sort_device(void* dev_keys, void* dev_tmp, uint64_t len, uint32_t e
     if (reinterpret_cast<uintptr_t>(dev_tmp) % elem_bytes) return fail(RDST_ERR_ALIGN, "tmp pointer not aligned to the element size");
     std::lock_guard<std::mutex> lock(g_mutex);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (elem_bytes == 4)
-        return run_pipeline<uint32_t, 4>(static_cast<uint32_t*>(dev_keys), static_cast<uint32_t*>(dev_tmp), len, kind, 0, 4, true, true, s, nullptr, nullptr);
-    return run_pipeline<uint64_t, 8>(static_cast<uint64_t*>(dev_keys), static_cast<uint64_t*>(dev_tmp), len, kind, 0, 8, true, true, s, nullptr, nullptr);
+    RDST_BY_WIDTH(elem_bytes, rc = (run_pipeline<K, LV>(static_cast<K*>(dev_keys), static_cast<K*>(dev_tmp), len, kind, 0, LV, true, true, s, nullptr, nullptr)));
+    return rc;
 }
 
 int rdst_hip_device_status(void* stream) {
@@ -1166,10 +1176,7 @@ int rdst_hip_all_level_counts(const void* dev_keys, uint64_t len, uint32_t elem_
     Layout L;
     char* ws = nullptr;
     // levels [0,0): histogram + scan only, no pass runs
-    if (elem_bytes == 4)
-        rc = run_pipeline<uint32_t, 4>(const_cast<uint32_t*>(static_cast<const uint32_t*>(dev_keys)), nullptr, len, kind, 0, 0, false, false, s, &L, &ws);
-    else
-        rc = run_pipeline<uint64_t, 8>(const_cast<uint64_t*>(static_cast<const uint64_t*>(dev_keys)), nullptr, len, kind, 0, 0, false, false, s, &L, &ws);
+    RDST_BY_WIDTH(elem_bytes, rc = (run_pipeline<K, LV>(const_cast<K*>(static_cast<const K*>(dev_keys)), nullptr, len, kind, 0, 0, false, false, s, &L, &ws)));
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(counts_out, ws + L.off_hist, sizeof(uint64_t) * levels * RADIX, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -1190,10 +1197,7 @@ int rdst_hip_scatter_level(const void* dev_src, void* dev_dst, uint64_t len, uin
     Layout L;
     char* ws = nullptr;
     // one un-skippable pass keys -> tmp, no copy-back: src is only read
-    if (elem_bytes == 4)
-        rc = run_pipeline<uint32_t, 4>(const_cast<uint32_t*>(static_cast<const uint32_t*>(dev_src)), static_cast<uint32_t*>(dev_dst), len, kind, level, level + 1, false, false, s, &L, &ws);
-    else
-        rc = run_pipeline<uint64_t, 8>(const_cast<uint64_t*>(static_cast<const uint64_t*>(dev_src)), static_cast<uint64_t*>(dev_dst), len, kind, level, level + 1, false, false, s, &L, &ws);
+    RDST_BY_WIDTH(elem_bytes, rc = (run_pipeline<K, LV>(const_cast<K*>(static_cast<const K*>(dev_src)), static_cast<K*>(dev_dst), len, kind, level, level + 1, false, false, s, &L, &ws)));
     if (rc) return rc;
     if (counts_out)
         HIP_TRY(hipMemcpyAsync(counts_out, ws + L.off_hist + sizeof(uint64_t) * (size_t)level * RADIX, sizeof(uint64_t) * RADIX, hipMemcpyDeviceToHost, s));
@@ -1235,10 +1239,7 @@ int rdst_hip_level_counts(const void* dev_keys, uint64_t len, uint32_t elem_byte
     const uint64_t cap = (uint64_t)D->cus * 8;
     if (blocks > cap) blocks = cap;
     const int shift = (int)level * 8;
-    if (elem_bytes == 4)
-        hipLaunchKernelGGL((level_counts_kernel<uint32_t>), dim3((uint32_t)blocks), dim3(256), 0, s, static_cast<const uint32_t*>(dev_keys), len, shift, (uint32_t)km.neg, (uint32_t)km.pos, d_counts, d_flag);
-    else
-        hipLaunchKernelGGL((level_counts_kernel<uint64_t>), dim3((uint32_t)blocks), dim3(256), 0, s, static_cast<const uint64_t*>(dev_keys), len, shift, (uint64_t)km.neg, (uint64_t)km.pos, d_counts, d_flag);
+    RDST_BY_WIDTH(elem_bytes, (void)LV; hipLaunchKernelGGL((level_counts_kernel<K>), dim3((uint32_t)blocks), dim3(256), 0, s, static_cast<const K*>(dev_keys), len, shift, (K)km.neg, (K)km.pos, d_counts, d_flag));
     HIP_TRY(hipGetLastError());
     uint32_t flag = 0;
     uint64_t first = 0, last = 0;

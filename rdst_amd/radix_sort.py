@@ -21,6 +21,10 @@ from .tuner import Algorithm, GpuTuner, LowMemoryTuner, SingleThreadedTuner, Tun
 
 # dtype name -> (rdst_key_kind, elem_bytes); LEVELS == elem_bytes for every built-in type
 _KEY_TABLE = {
+    "uint8": (_lib.RDST_KEY_UNSIGNED, 1),
+    "uint16": (_lib.RDST_KEY_UNSIGNED, 2),
+    "int8": (_lib.RDST_KEY_SIGNED, 1),
+    "int16": (_lib.RDST_KEY_SIGNED, 2),
     "uint32": (_lib.RDST_KEY_UNSIGNED, 4),
     "uint64": (_lib.RDST_KEY_UNSIGNED, 8),
     "int32": (_lib.RDST_KEY_SIGNED, 4),
@@ -162,7 +166,7 @@ def top_level_counts(data):
 
 
 def _same_width_int(dt):
-    return {4: np.int32, 8: np.int64}[np.dtype(dt).itemsize]
+    return {1: np.int8, 2: np.int16, 4: np.int32, 8: np.int64}[np.dtype(dt).itemsize]
 
 
 def level_counts(keys, level):

@@ -100,7 +100,7 @@ def sharded_sort(local_keys, group=None, engine=None, return_info: bool = False)
     grouped = engine.scatter_top_level(local_keys)
     # 5. exchange
     inbox = engine.empty(sum(recv), local_keys)
-    as_int = {4: torch.int32, 8: torch.int64}[local_keys.element_size()]
+    as_int = {1: torch.int8, 2: torch.int16, 4: torch.int32, 8: torch.int64}[local_keys.element_size()]
     if via_host:
         host_in = torch.empty(sum(recv), dtype=as_int)
         dist.all_to_all_single(host_in, grouped.view(as_int).cpu(), output_split_sizes=recv, input_split_sizes=send,

@@ -49,6 +49,7 @@ int main() {
     for (std::size_t n : {0ul, 1ul, 2ul, 129ul, 100000ul, 3000001ul}) {
         bad += check_int<std::uint32_t>(n, 1) + check_int<std::uint64_t>(n, 2) + check_int<std::int32_t>(n, 3) + check_int<std::int64_t>(n, 4);
         bad += check_float<float, std::uint32_t>(n, 5) + check_float<double, std::uint64_t>(n, 6);
+        bad += check_int<std::uint8_t>(n, 7) + check_int<std::int16_t>(n, 8);
     }
     // a CPU tuner cannot be honoured here: throws, data untouched
     std::vector<std::uint32_t> keep = {9, 8, 7, 6};

@@ -8,6 +8,7 @@ SEED_C3 = 0x5D570003
 SEED_C4 = 0x5D570004
 
 DTYPES = ("uint32", "uint64", "int32", "int64", "float32", "float64")
+SMALL_DTYPES = ("uint8", "uint16", "int8", "int16")
 
 
 def uint_view(a):
@@ -95,5 +96,5 @@ def to_device(a):
 
 def to_host(t, dtype):
     import torch
-    it = {4: torch.int32, 8: torch.int64}[np.dtype(dtype).itemsize]
+    it = {1: torch.int8, 2: torch.int16, 4: torch.int32, 8: torch.int64}[np.dtype(dtype).itemsize]
     return t.view(it).cpu().numpy().view(dtype)

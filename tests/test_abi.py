@@ -36,6 +36,7 @@ def test_argument_validation_happens_before_any_device_call(hiplib):
     assert hiplib.rdst_hip_sort(p, 8, 4, 0, 0, None) == -1
     assert b"level" in hiplib.rdst_hip_last_error()
     assert hiplib.rdst_hip_sort(p, 8, 3, 0, 3, None) == -2          # unsupported width
+    assert hiplib.rdst_hip_sort(p, 8, 2, 2, 2, None) == -2          # no 2-byte float key
     assert hiplib.rdst_hip_sort(p, 8, 4, 7, 4, None) == -1          # unknown kind
     assert hiplib.rdst_hip_sort(None, 8, 4, 0, 4, None) == -1       # null pointer
     assert hiplib.rdst_hip_sort(ctypes.c_void_p(p.value + 2), 4, 4, 0, 4, None) == -6  # misaligned

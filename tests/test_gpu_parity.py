@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import (DTYPES, gen_inputs, mapped_key, random_bits, reference_sorted, same_bits, to_device, to_host,
+from helpers import (DTYPES, SMALL_DTYPES, gen_inputs, mapped_key, random_bits, reference_sorted, same_bits, to_device, to_host,
                      u32_patterns)
 
 pytestmark = pytest.mark.gpu
@@ -62,6 +62,30 @@ def test_sort_matches_oracle_over_sizes(gpu, oracle, dtype):
         got = _device_sort(gpu, a)
         assert same_bits(got, exp), (dtype, n)
         assert same_bits(exp, reference_sorted(a))  # oracle vs independent numpy, same input
+
+
+@pytest.mark.parametrize("dtype", SMALL_DTYPES)
+def test_narrow_key_types(gpu, oracle, dtype):
+    """u8 / u16 / i8 / i16 (src/radix_key_impl.rs:3-19, :87-103): one- and two-level keys."""
+    levels = np.dtype(dtype).itemsize
+    for i, n in enumerate((0, 1, 2, 129, 18431, 18432, 18433, 300_000, 4_000_001)):
+        a = random_bits(n, dtype, seed=300 + i).copy()
+        exp = a.copy()
+        oracle.sort(exp, threads=4)
+        assert same_bits(_device_sort(gpu, a), exp), (dtype, n)
+        assert same_bits(exp, reference_sorted(a))
+    a = random_bits(1_000_000, dtype, seed=9).copy()
+    t = to_device(a)
+    for level in range(levels):
+        c, srt, first, last = gpu.level_counts(t, level)
+        oc, osrt, ofirst, olast = oracle.get_counts_with_ends(a, level)
+        assert np.array_equal(np.asarray(c, dtype=np.uint64), oc) and (srt, first, last) == (osrt, ofirst, olast)
+        dst, _ = gpu.scatter_level(t, level)
+        exp, _ = oracle.out_of_place_sort(a, level, "plain")
+        assert same_bits(to_host(dst, dtype), exp)
+    h = a.copy()
+    gpu.radix_sort_unstable(h)  # host entry point
+    assert same_bits(h, reference_sorted(a))
 
 
 @pytest.mark.parametrize("dtype,shift", [("uint32", 16), ("uint64", 32), ("int32", 16), ("int64", 32)])

@@ -10,8 +10,9 @@ def test_key_info_table():
     assert rdst_amd.key_info("int64") == (1, 8, 8)
     assert rdst_amd.key_info("float32") == (2, 4, 4)
     assert rdst_amd.key_info("torch.float64") == (2, 8, 8)
+    assert rdst_amd.key_info("uint16") == (0, 2, 2) and rdst_amd.key_info("int8") == (1, 1, 1)
     with pytest.raises(TypeError):
-        rdst_amd.key_info("uint16")  # not built for the device path yet
+        rdst_amd.key_info("float16")  # no RadixKey for it in the reference either
 
 
 def test_len_le_1_is_a_noop_without_a_device(hiplib):
