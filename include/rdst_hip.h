@@ -42,7 +42,7 @@ typedef enum {
 typedef enum {
     RDST_OK              = 0,
     RDST_ERR_ARG         = -1, /* bad pointer / size / kind / levels (LEVELS == 0 panics in rdst: radix_sort_builder.rs:22) */
-    RDST_ERR_UNSUPPORTED = -2, /* element width / kind not built for the device path (built: 1, 2, 4, 8-byte integers, f32, f64) */
+    RDST_ERR_UNSUPPORTED = -2, /* element width / kind not built for the device path (built: 1-, 2-, 4-, 8-, 16-byte integers, f32, f64) */
     RDST_ERR_HIP         = -3, /* a HIP runtime call failed; see rdst_hip_last_error() */
     RDST_ERR_NO_DEVICE   = -4, /* no usable gfx950 device */
     RDST_ERR_DEVICE      = -5, /* a kernel reported failure through the workspace error word (bounded spin expired) */

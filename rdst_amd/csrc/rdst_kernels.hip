@@ -65,9 +65,11 @@ struct Plan {
     uint32_t executed;                // number of passes executed
 };
 
+typedef unsigned __int128 u128;  // u128 / i128 keys (src/radix_key_impl.rs:39-46, :123-130)
+
 struct KeyMap {  // order-preserving map as two xor masks (src/radix_key_impl.rs)
-    uint64_t neg;  // xor applied when the sign bit is set
-    uint64_t pos;  // xor applied when it is clear
+    u128 neg;  // xor applied when the sign bit is set
+    u128 pos;  // xor applied when it is clear
 };
 
 template <typename K>
@@ -101,9 +103,11 @@ __device__ __forceinline__ K lane_below(K x) {
     if constexpr (sizeof(K) <= 4) {
         return (K)__builtin_amdgcn_mov_dpp((int)x, WAVE_SHR1, 0xf, 0xf, false);
     } else {
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)x, WAVE_SHR1, 0xf, 0xf, false);
-        const uint32_t hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(x >> 32), WAVE_SHR1, 0xf, 0xf, false);
-        return (K)lo | ((K)hi << 32);
+        K r = 0;
+#pragma unroll
+        for (int w = 0; w < (int)sizeof(K) / 4; ++w)
+            r |= (K)(uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(x >> (32 * w)), WAVE_SHR1, 0xf, 0xf, false) << (32 * w);
+        return r;
     }
 }
 
@@ -141,7 +145,7 @@ template <typename K, int LEVELS, int VEC>
 __global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const K* __restrict__ keys, uint64_t n, K neg, K pos,
                                                             unsigned long long* __restrict__ hist,
                                                             uint32_t* __restrict__ inversion /* set if keys[i-1] > keys[i] anywhere */) {
-    constexpr int COPIES = LEVELS <= 4 ? 32 : 16;
+    constexpr int COPIES = LEVELS <= 4 ? 32 : (LEVELS <= 8 ? 16 : 8);
     constexpr int WORDS = LEVELS * RADIX * COPIES;  // 32768 words = 128 KiB
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* s_h = reinterpret_cast<uint32_t*>(smem);
@@ -296,7 +300,7 @@ __device__ __forceinline__ uint32_t peers_below(uint32_t word, int bit0) {
 
 template <typename K>
 __device__ __forceinline__ uint32_t digit_word(K mapped, int shift) {  // 32-bit half that holds the digit
-    if constexpr (sizeof(K) == 8) return (uint32_t)(mapped >> (shift & 32));
+    if constexpr (sizeof(K) > 4) return (uint32_t)(mapped >> (shift & ~31));
     else return (uint32_t)mapped;
 }
 
@@ -706,6 +710,8 @@ constexpr PassCfg kPassCfgs[] = {
 };
 constexpr int kNumPassCfgs = sizeof(kPassCfgs) / sizeof(kPassCfgs[0]);
 constexpr int default_cfg(uint32_t elem_bytes) { return elem_bytes == 8 ? 3 : 2; }
+// keys per thread for a key width, from the table's 8-byte figure: same bytes per thread
+constexpr int kpt_for(int kpt8, size_t elem_bytes) { return elem_bytes <= 4 ? kpt8 * 2 : (elem_bytes == 8 ? kpt8 : (kpt8 / 2) & ~1); }
 
 struct Tuning { int pass_cfg = -1; int hist_bpc = 0; bool profiling = false; };  // pass_cfg < 0: default_cfg()
 uint32_t g_ablate = 0;  // only ever set by the RDST_EXPERIMENTS build
@@ -743,7 +749,7 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 int tile_keys(int cfg, uint32_t elem_bytes) {
     const PassCfg& p = kPassCfgs[cfg];
-    return p.nwaves * 64 * (elem_bytes == 8 ? p.kpt8 : p.kpt4);
+    return p.nwaves * 64 * kpt_for(p.kpt8, elem_bytes);
 }
 
 Layout make_layout(uint64_t n, uint32_t elem_bytes, uint32_t levels, int cfg) {
@@ -829,8 +835,8 @@ int prof_mark(DeviceState& D, hipStream_t s) {
 }
 
 KeyMap key_map_for(rdst_key_kind kind, uint32_t elem_bytes) {
-    const uint64_t msb = 1ull << (elem_bytes * 8 - 1);
-    const uint64_t ones = elem_bytes == 8 ? ~0ull : ((1ull << (elem_bytes * 8)) - 1);
+    const u128 msb = (u128)1 << (elem_bytes * 8 - 1);
+    const u128 ones = elem_bytes == 16 ? ~(u128)0 : (((u128)1 << (elem_bytes * 8)) - 1);
     switch (kind) {
         case RDST_KEY_SIGNED: return {msb, msb};
         case RDST_KEY_FLOAT: return {ones, msb};
@@ -841,7 +847,7 @@ KeyMap key_map_for(rdst_key_kind kind, uint32_t elem_bytes) {
 template <typename K, int LEVELS, int VEC>
 int launch_hist_v(const K* keys, uint64_t n, uint32_t blocks, KeyMap km, unsigned long long* hist, uint32_t* inversion,
                   hipStream_t s) {
-    constexpr size_t lds = (size_t)LEVELS * RADIX * (LEVELS <= 4 ? 32 : 16) * sizeof(uint32_t);
+    constexpr size_t lds = (size_t)LEVELS * RADIX * (LEVELS <= 4 ? 32 : (LEVELS <= 8 ? 16 : 8)) * sizeof(uint32_t);
     static bool attr_set = false;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&hist_kernel<K, LEVELS, VEC>),
@@ -895,12 +901,11 @@ int launch_pass_t(K* keys, K* tmp, uint64_t n, int level, const Layout& L, char*
 
 template <typename K, typename S, bool MAPPED, bool NARROW>
 int launch_pass_s(int cfg, K* keys, K* tmp, uint64_t n, int level, const Layout& L, char* ws, KeyMap km, hipStream_t s) {
-    constexpr int F = sizeof(K) <= 4 ? 2 : 1;  // keys of up to 4 bytes: twice the keys per thread
     switch (cfg) {
-        case 0: return launch_pass_t<K, S, 8 * F, 8, 1, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, s);
-        case 1: return launch_pass_t<K, S, 12 * F, 8, 2, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, s);
-        case 2: return launch_pass_t<K, S, 12 * F, 12, 2, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, s);
-        case 3: return launch_pass_t<K, S, 14 * F, 12, 2, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, s);
+        case 0: return launch_pass_t<K, S, kpt_for(8, sizeof(K)), 8, 1, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, s);
+        case 1: return launch_pass_t<K, S, kpt_for(12, sizeof(K)), 8, 2, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, s);
+        case 2: return launch_pass_t<K, S, kpt_for(12, sizeof(K)), 12, 2, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, s);
+        case 3: return launch_pass_t<K, S, kpt_for(14, sizeof(K)), 12, 2, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, s);
     }
     return fail(RDST_ERR_ARG, "bad pass config");
 }
@@ -997,13 +1002,14 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
         case 1: { using K = uint8_t; constexpr int LV = 1; CALL; } break;          \
         case 2: { using K = uint16_t; constexpr int LV = 2; CALL; } break;         \
         case 4: { using K = uint32_t; constexpr int LV = 4; CALL; } break;         \
-        default: { using K = uint64_t; constexpr int LV = 8; CALL; } break;        \
+        case 8: { using K = uint64_t; constexpr int LV = 8; CALL; } break;         \
+        default: { using K = u128; constexpr int LV = 16; CALL; } break;           \
     }
 
 int check_common(const void* p, uint64_t len, uint32_t elem_bytes, rdst_key_kind kind, uint32_t levels) {
-    if (elem_bytes != 1 && elem_bytes != 2 && elem_bytes != 4 && elem_bytes != 8)
-        return fail(RDST_ERR_UNSUPPORTED, "device path is built for 1-, 2-, 4- and 8-byte keys");
-    if (kind == RDST_KEY_FLOAT && elem_bytes < 4) return fail(RDST_ERR_UNSUPPORTED, "float keys are f32 / f64");
+    if (elem_bytes != 1 && elem_bytes != 2 && elem_bytes != 4 && elem_bytes != 8 && elem_bytes != 16)
+        return fail(RDST_ERR_UNSUPPORTED, "device path is built for 1-, 2-, 4-, 8- and 16-byte keys");
+    if (kind == RDST_KEY_FLOAT && elem_bytes != 4 && elem_bytes != 8) return fail(RDST_ERR_UNSUPPORTED, "float keys are f32 / f64");
     if (levels == 0) return fail(RDST_ERR_ARG, "RadixKey must have at least 1 level");
     if (levels != elem_bytes) return fail(RDST_ERR_ARG, "levels must equal the element width for built-in key types");
     if ((int)kind < 0 || (int)kind > 2) return fail(RDST_ERR_ARG, "unknown key kind");
@@ -1101,7 +1107,7 @@ int rdst_hip_profile_run(int run, float* out_ms, uint32_t capacity, uint32_t* n_
 }
 
 uint64_t rdst_hip_workspace_bytes(uint64_t len, uint32_t elem_bytes) {
-    if (elem_bytes != 1 && elem_bytes != 2 && elem_bytes != 4 && elem_bytes != 8) return 0;
+    if (elem_bytes != 1 && elem_bytes != 2 && elem_bytes != 4 && elem_bytes != 8 && elem_bytes != 16) return 0;
     int cfg = g_tuning.pass_cfg;
     if (cfg < 0 || cfg >= kNumPassCfgs) cfg = default_cfg(elem_bytes);
     return make_layout(len, elem_bytes, elem_bytes, cfg).total;
@@ -1242,7 +1248,7 @@ int rdst_hip_level_counts(const void* dev_keys, uint64_t len, uint32_t elem_byte
     RDST_BY_WIDTH(elem_bytes, (void)LV; hipLaunchKernelGGL((level_counts_kernel<K>), dim3((uint32_t)blocks), dim3(256), 0, s, static_cast<const K*>(dev_keys), len, shift, (K)km.neg, (K)km.pos, d_counts, d_flag));
     HIP_TRY(hipGetLastError());
     uint32_t flag = 0;
-    uint64_t first = 0, last = 0;
+    u128 first = 0, last = 0;
     HIP_TRY(hipMemcpyAsync(counts, d_counts, sizeof(uint64_t) * RADIX, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(&flag, d_flag, sizeof flag, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(&first, dev_keys, elem_bytes, hipMemcpyDeviceToHost, s));
@@ -1250,9 +1256,9 @@ int rdst_hip_level_counts(const void* dev_keys, uint64_t len, uint32_t elem_byte
     rc = workspace_release(*D, s);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(s));
-    auto host_digit = [&](uint64_t raw) -> uint8_t {
-        const uint64_t sign = raw >> (elem_bytes * 8 - 1) & 1;
-        const uint64_t m = raw ^ (sign ? km.neg : km.pos);
+    auto host_digit = [&](u128 raw) -> uint8_t {
+        const bool sign = ((raw >> (elem_bytes * 8 - 1)) & 1) != 0;
+        const u128 m = raw ^ (sign ? km.neg : km.pos);
         return (uint8_t)(m >> shift);
     };
     if (already_sorted) *already_sorted = flag ? 0 : 1;

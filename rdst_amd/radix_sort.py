@@ -31,6 +31,10 @@ _KEY_TABLE = {
     "int64": (_lib.RDST_KEY_SIGNED, 8),
     "float32": (_lib.RDST_KEY_FLOAT, 4),
     "float64": (_lib.RDST_KEY_FLOAT, 8),
+    # no numpy / torch dtype exists for these: pass key="u128" / "i128" with a container of shape
+    # (n, 2) whose rows are the little-endian 64-bit limbs [low, high] of one key
+    "u128": (_lib.RDST_KEY_UNSIGNED, 16),
+    "i128": (_lib.RDST_KEY_SIGNED, 16),
 }
 
 
@@ -52,23 +56,36 @@ def _stream_handle(tensor):
     return ctypes.c_void_p(torch.cuda.current_stream(tensor.device).cuda_stream)
 
 
-def sort_device_tensor(keys, tmp=None, check=True):
-    """``rdst_hip_sort_device`` on a 1-D contiguous HIP tensor.  ``tmp``: optional scratch
+def _wide(key):
+    return key in ("u128", "i128")
+
+
+def _check_wide_shape(shape, itemsize):
+    if len(shape) != 2 or shape[1] * itemsize != 16:
+        raise ValueError("a 128-bit key container has shape (n, 2) with 8-byte limbs [low, high]")
+
+
+def sort_device_tensor(keys, tmp=None, check=True, key=None):
+    """``rdst_hip_sort_device`` on a 1-D contiguous HIP tensor (``key="u128"/"i128"``: shape (n, 2)).  ``tmp``: optional scratch
     tensor of the same shape/dtype (allocated when omitted).  With ``check`` the call blocks
     and raises if a kernel reported failure; without it the sort stays asynchronous on the
     tensor's current stream (call :func:`device_status` later)."""
     import torch
     if not keys.is_cuda:
         raise ValueError("sort_device_tensor needs a tensor on a HIP device")
-    if keys.dim() != 1 or not keys.is_contiguous():
+    if _wide(key):
+        _check_wide_shape(tuple(keys.shape), keys.element_size())
+    elif keys.dim() != 1:
         raise ValueError("keys must be a contiguous 1-D tensor (rdst sorts a slice)")
-    kind, nbytes, levels = key_info(keys.dtype)
-    n = keys.numel()
+    if not keys.is_contiguous():
+        raise ValueError("keys must be a contiguous 1-D tensor (rdst sorts a slice)")
+    kind, nbytes, levels = key_info(key if key else keys.dtype)
+    n = keys.numel() * keys.element_size() // nbytes
     if n <= 1:
         return
     if tmp is None:
         tmp = torch.empty_like(keys)
-    elif tmp.dtype != keys.dtype or tmp.numel() < n or not tmp.is_contiguous() or tmp.device != keys.device:
+    elif tmp.dtype != keys.dtype or tmp.numel() < keys.numel() or not tmp.is_contiguous() or tmp.device != keys.device:
         raise ValueError("tmp must be a contiguous tensor of the same dtype/device with at least len elements")
     lib = _lib.load()
     with torch.cuda.device(keys.device):
@@ -87,16 +104,20 @@ def device_status(device=None):
         _lib.check(lib.rdst_hip_device_status(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
 
-def sort_host_array(arr, device=-1):
+def sort_host_array(arr, device=-1, key=None):
     """``rdst_hip_sort`` on a host numpy array (H2D, device sort, D2H), in place."""
-    if not isinstance(arr, np.ndarray) or arr.ndim != 1 or not arr.flags.c_contiguous or not arr.flags.writeable:
+    if not isinstance(arr, np.ndarray) or not arr.flags.c_contiguous or not arr.flags.writeable:
         raise ValueError("need a writeable C-contiguous 1-D numpy array (rdst sorts a mutable slice)")
-    kind, nbytes, levels = key_info(arr.dtype.name)
-    if arr.size <= 1:
+    if _wide(key):
+        _check_wide_shape(arr.shape, arr.dtype.itemsize)
+    elif arr.ndim != 1:
+        raise ValueError("need a writeable C-contiguous 1-D numpy array (rdst sorts a mutable slice)")
+    kind, nbytes, levels = key_info(key if key else arr.dtype.name)
+    if arr.nbytes // nbytes <= 1:
         return
     lib = _lib.load()
     opts = _lib.HipOptsC(int(device), 0, 0)
-    _lib.check(lib.rdst_hip_sort(ctypes.c_void_p(arr.ctypes.data), arr.size, nbytes, kind, levels, ctypes.byref(opts)))
+    _lib.check(lib.rdst_hip_sort(ctypes.c_void_p(arr.ctypes.data), arr.nbytes // nbytes, nbytes, kind, levels, ctypes.byref(opts)))
 
 
 class RadixSortBuilder:
@@ -105,8 +126,9 @@ class RadixSortBuilder:
     does not ship, so on the device route they only take part in the top-level
     ``pick_algorithm`` call (a tuner that does not return a ``Gpu*`` algorithm raises)."""
 
-    def __init__(self, data):
+    def __init__(self, data, key=None):
         self._data = data
+        self._key = key
         self._multi_threaded = True
         self._tuner: Tuner = GpuTuner(0)
 
@@ -130,6 +152,10 @@ class RadixSortBuilder:
 
     def _len_and_levels(self):
         d = self._data
+        if self._key:
+            _, nbytes, levels = key_info(self._key)
+            total = d.numel() * d.element_size() if _is_torch_tensor(d) else d.nbytes
+            return total // nbytes, levels
         if _is_torch_tensor(d):
             return d.numel(), key_info(d.dtype)[2]
         return d.size, key_info(d.dtype.name)[2]
@@ -139,6 +165,8 @@ class RadixSortBuilder:
         if n <= 1:  # radix_sort_builder.rs:151
             return
         if not isinstance(self._tuner, GpuTuner):
+            if self._key:
+                raise NotImplementedError("custom tuners are wired for the dtype-described key types only")
             # top-level pick_algorithm, as Sorter::handle_chunk does (src/sorter.rs:67-76)
             counts = top_level_counts(self._data)
             algo = self._tuner.pick_algorithm(
@@ -148,9 +176,9 @@ class RadixSortBuilder:
                     f"tuner picked {Algorithm(algo).name}: the CPU algorithms stay in the reference crate; "
                     "this package implements the device route (Algorithm.GpuLsd) only")
         if _is_torch_tensor(self._data):
-            sort_device_tensor(self._data)
+            sort_device_tensor(self._data, key=self._key)
         else:
-            sort_host_array(self._data)
+            sort_host_array(self._data, key=self._key)
 
 
 def top_level_counts(data):
@@ -212,16 +240,17 @@ def scatter_level(src, level, dst=None):
     return dst, counts
 
 
-def radix_sort_builder(data) -> RadixSortBuilder:
-    """``RadixSort::radix_sort_builder`` (src/radix_sort.rs:29-31 / :42-44)."""
-    n_levels = key_info(data.dtype if _is_torch_tensor(data) else data.dtype.name)[2]
+def radix_sort_builder(data, key=None) -> RadixSortBuilder:
+    """``RadixSort::radix_sort_builder`` (src/radix_sort.rs:29-31 / :42-44).  ``key``: "u128" / "i128"
+    for (n, 2) limb containers; otherwise the key type is the container's dtype."""
+    n_levels = key_info(key if key else (data.dtype if _is_torch_tensor(data) else data.dtype.name))[2]
     assert n_levels != 0, "RadixKey must have at least 1 level"  # radix_sort_builder.rs:22
-    return RadixSortBuilder(data)
+    return RadixSortBuilder(data, key)
 
 
-def radix_sort_unstable(data) -> None:
+def radix_sort_unstable(data, key=None) -> None:
     """``RadixSort::radix_sort_unstable`` (src/radix_sort.rs:25-27 / :38-40)."""
-    radix_sort_builder(data).sort()
+    radix_sort_builder(data, key).sort()
 
 
 def set_tuning(pass_config=-1, hist_blocks_per_cu=0):

@@ -53,7 +53,7 @@ def test_workspace_size_is_reported(hiplib):
     big = hiplib.rdst_hip_workspace_bytes(1_000_000_000, 4)
     assert 0 < small < big
     assert big < 1_000_000_000  # status words are a small fraction of the key bytes (4 GB)
-    assert hiplib.rdst_hip_workspace_bytes(10, 3) == 0
+    assert hiplib.rdst_hip_workspace_bytes(10, 3) == 0 and hiplib.rdst_hip_workspace_bytes(10, 16) > 0
 
 
 def test_tuner_tables_match_oracle_on_a_grid(hiplib, oracle):

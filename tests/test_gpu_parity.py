@@ -88,6 +88,29 @@ def test_narrow_key_types(gpu, oracle, dtype):
     assert same_bits(h, reference_sorted(a))
 
 
+@pytest.mark.parametrize("kind", ["u128", "i128"])
+def test_128_bit_keys(gpu, oracle, kind):
+    """u128 / i128 (src/radix_key_impl.rs:39-46, :123-130): 16 levels, keys as [low, high] limbs."""
+    import torch
+    rng = np.random.default_rng(128)
+    for n in (0, 1, 2, 129, 4607, 4608, 4609, 100_003, 2_000_001):
+        a = rng.integers(0, 1 << 64, size=(n, 2), dtype=np.uint64)
+        if n > 1000:
+            a[: n // 2, 1] = a[0, 1]  # equal high limbs: the low levels decide
+        exp = a.copy()
+        oracle.sort(exp, threads=4, kind=kind)
+        t = torch.from_numpy(a.view(np.int64).copy()).cuda()
+        gpu.radix_sort_unstable(t, key=kind)
+        assert np.array_equal(t.cpu().numpy().view(np.uint64), exp), (kind, n)
+        if n in (129, 100_003):
+            h = a.copy()
+            gpu.radix_sort_unstable(h, key=kind)  # host entry point
+            assert np.array_equal(h, exp)
+            vals = [(int(hi) << 64) | int(lo) for lo, hi in exp.tolist()]
+            key = (lambda v: v ^ (1 << 127)) if kind == "i128" else (lambda v: v)
+            assert vals == sorted(vals, key=key)  # oracle vs Python big integers
+
+
 @pytest.mark.parametrize("dtype,shift", [("uint32", 16), ("uint64", 32), ("int32", 16), ("int64", 32)])
 def test_bimodal_shift_inputs(gpu, oracle, dtype, shift):
     """gen_inputs (src/test_utils.rs:51-61): empty high / low levels -> level skipping on device."""
