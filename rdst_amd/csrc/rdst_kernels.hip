@@ -15,9 +15,9 @@
 //   K4 key map            fused into K1/K3 digit extraction.     src/radix_key_impl.rs:3-185
 //   K6 level_counts_kernel single-level histogram + already_sorted flag (parity hook)
 //
-// Data layout in HBM: keys are a dense array of K (u32 / u64 bit patterns; signed and float
-// keys stay in their raw encoding in memory, the order-preserving map is applied in registers
-// for digit extraction only).  `keys` and `tmp` ping-pong per executed pass.  The workspace
+// Data layout in HBM: keys are a dense array of K (unsigned 1-, 2-, 4-, 8- or 16-byte bit patterns;
+// signed and float keys stay in their raw encoding in memory, the order-preserving map is applied
+// in registers for digit extraction only).  `keys` and `tmp` ping-pong per executed pass.  The workspace
 // holds, per sort: an error word, per-level tile tickets, the plan, histograms u64[L][256],
 // look-back status words (u32 when n < 2^30, else u64) [L][tiles][256], and the bucket start
 // table u64[L][256].  A per-range ("multi-chain") offset table is NOT possible with one
