@@ -152,6 +152,11 @@ uint64_t rdst_hip_workspace_bytes(uint64_t len, uint32_t elem_bytes);
  * built-in).  Not part of the reference surface. */
 int rdst_hip_set_tuning(int pass_config, int hist_blocks_per_cu);
 
+/* Experiment knob: enabled == 0 makes every scatter pass use ONE look-back chain over all of its
+ * tiles instead of splitting its source into segments with a chain each (default: split).
+ * Results are identical either way.  Not part of the reference surface. */
+int rdst_hip_set_chain_split(int enabled);
+
 /* Per-kernel device timing for benchmarks.  While enabled, every pipeline (sort / hook call)
  * records HIP events on its own stream between its launches and appends one "run" to a
  * per-device list; enabling again clears the list.  rdst_hip_profile_run blocks until run

@@ -61,8 +61,32 @@ constexpr uint32_t ERR_SCATTER_RANGE = 2;  // a computed destination fell outsid
 struct Plan {
     uint32_t skip[MAX_LEVELS];        // pass would move nothing (one bin holds every key)
     uint32_t src_is_tmp[MAX_LEVELS];  // which buffer the pass reads
+    uint32_t chain_mode[MAX_LEVELS];  // how the pass's source splits into look-back chains (CHAIN_*)
     uint32_t result_in_tmp;           // where the data sits after the last executed pass
     uint32_t executed;                // number of passes executed
+};
+
+// Look-back chains.  One chain over all tiles makes every tile walk back over ~(status latency /
+// tile start interval) predecessor rows, and those re-reads are fabric traffic on the scale of
+// the keys themselves.  A pass therefore splits its source into CHAINS contiguous
+// segments whose digit counts are known BEFORE the pass, each with its own chain: the start rate
+// per chain, and with it the walk depth, drops CHAINS-fold.  Segment counts that one read of
+// the unsorted keys can give (K1):
+//   CHAIN_POS   first executed pass: segment = position range of the input (K1's pieces)
+//   CHAIN_PAIR  pass p right after pass p-1: segment = the buckets of a group of p-1 digits, its
+//               counts = the joint histogram (digit_{p-1} group, digit_p) — a property of the key
+//               multiset, unlike range counts of a later pass's (permuted) source
+//   CHAIN_ONE   anything else (a skipped level in between): one chain
+constexpr int CHAINS = 8;
+constexpr uint32_t CHAIN_ONE = 0, CHAIN_POS = 1, CHAIN_PAIR = 2;
+constexpr uint32_t TILE_ALIGN = 32;  // keys; every tile but a chain's first starts on a multiple
+
+struct LevelChains {  // written by K2 for every executed level, read by K3's ticket holder
+    uint64_t seg_lo[CHAINS + 1];  // chain c covers source indices [seg_lo[c], seg_lo[c+1])
+    uint32_t row0[CHAINS];        // first status row of chain c
+    uint32_t ntiles[CHAINS];      // tiles of chain c
+    uint32_t total_tiles;
+    uint32_t pad[3];
 };
 
 typedef unsigned __int128 u128;  // u128 / i128 keys (src/radix_key_impl.rs:39-46, :123-130)
@@ -141,12 +165,43 @@ __device__ __forceinline__ uint32_t lanes_below(uint64_t mask) {  // popcount(ma
 // ------------------------------------------------------------------------------------------
 constexpr int HIST_THREADS = 1024;
 
-template <typename K, int LEVELS, int VEC>
+// K1's grid is cut into CHAINS position ranges of whole pieces: block b counts for range b*CHAINS/grid
+__host__ __device__ inline uint32_t hist_range_of(uint32_t block, uint32_t grid) { return (uint32_t)((uint64_t)block * CHAINS / grid); }
+__host__ __device__ inline uint32_t hist_first_block(uint32_t range, uint32_t grid) {  // smallest b with hist_range_of(b) >= range
+    return (uint32_t)(((uint64_t)range * grid + CHAINS - 1) / CHAINS);
+}
+__host__ __device__ inline uint64_t hist_piece(uint64_t n, uint32_t grid, uint64_t gran) {
+    uint64_t piece = (n + grid - 1) / grid;
+    return (piece + gran - 1) / gran * gran;
+}
+
+// LDS plan of K1.  PAIR == false: one [256] table per level, COPIES bank columns each.
+// PAIR == true (the chain split needs it): level 0 as before, and for every level l >= 1 a joint
+// table over (digit_l, group of digit_{l-1}) — entry digit_l * CHAINS + (digit_{l-1} >> 5), one
+// 11-bit field of the key — with PCOPIES bank columns; its sum over the groups is level l's plain
+// histogram, so a key still costs one LDS atomic per level.
+template <int LEVELS, bool PAIR>
+struct HistPlan {
+    static constexpr int GROUP_BITS = 3;
+    static_assert((1 << GROUP_BITS) == CHAINS, "digit groups == chains");
+    static constexpr int COPIES = !PAIR ? (LEVELS <= 4 ? 32 : (LEVELS <= 8 ? 16 : 8))
+                                        : (LEVELS <= 4 ? 32 : (LEVELS <= 8 ? 16 : 8));  // level 0 (all levels if !PAIR)
+    static constexpr int PCOPIES = LEVELS <= 2 ? 8 : (LEVELS <= 4 ? 4 : (LEVELS <= 8 ? 2 : 1));
+    static constexpr int PLAIN_LEVELS = PAIR ? 1 : LEVELS;
+    static constexpr int PAIR_LEVELS = PAIR ? LEVELS - 1 : 0;
+    static constexpr int PAIR_BASE = PLAIN_LEVELS * RADIX * COPIES;          // first word of the joint tables
+    static constexpr int PAIR_WORDS = RADIX * CHAINS * PCOPIES;              // words per joint table
+    static constexpr int WORDS = PAIR_BASE + PAIR_LEVELS * PAIR_WORDS;       // <= 32768 words = 128 KiB
+    static_assert(WORDS <= 32768, "K1 LDS budget");
+};
+
+template <typename K, int LEVELS, int VEC, bool PAIR>
 __global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const K* __restrict__ keys, uint64_t n, K neg, K pos,
-                                                            unsigned long long* __restrict__ hist,
+                                                            unsigned long long* __restrict__ hpos /* [LEVELS][CHAINS][256]: counts per position range */,
+                                                            unsigned long long* __restrict__ hpair /* [LEVELS][CHAINS][256]: counts per group of the previous digit (PAIR) */,
                                                             uint32_t* __restrict__ inversion /* set if keys[i-1] > keys[i] anywhere */) {
-    constexpr int COPIES = LEVELS <= 4 ? 32 : (LEVELS <= 8 ? 16 : 8);
-    constexpr int WORDS = LEVELS * RADIX * COPIES;  // 32768 words = 128 KiB
+    using P = HistPlan<LEVELS, PAIR>;
+    constexpr int COPIES = P::COPIES, PCOPIES = P::PCOPIES, WORDS = P::WORDS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* s_h = reinterpret_cast<uint32_t*>(smem);
     const int tid = threadIdx.x;
@@ -154,12 +209,12 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const K* __restrict_
     __syncthreads();
 
     constexpr uint64_t GRAN = (uint64_t)HIST_THREADS * VEC * 4;  // one unrolled sweep of the block
-    uint64_t piece = (n + gridDim.x - 1) / gridDim.x;
-    piece = (piece + GRAN - 1) / GRAN * GRAN;
+    const uint64_t piece = hist_piece(n, gridDim.x, GRAN);
     const uint64_t p_begin = (uint64_t)blockIdx.x * piece;
     uint64_t p_end = p_begin + piece;
     if (p_end > n) p_end = n;
-    uint32_t* mine = s_h + (tid & (COPIES - 1));  // my bank column
+    uint32_t* mine = s_h + (tid & (COPIES - 1));                    // my bank column, plain tables
+    uint32_t* mine_p = s_h + P::PAIR_BASE + (tid & (PCOPIES - 1));  // and of the joint tables
 
     // Besides counting, the sweep looks for an inversion in mapped-key order: a slice that is
     // already sorted needs no pass at all (the whole-slice form of rdst's already_sorted exits,
@@ -175,7 +230,13 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const K* __restrict_
         inv |= before > m;
 #endif
 #pragma unroll
-        for (int l = 0; l < LEVELS; ++l) atomicAdd(&mine[(l * RADIX + digit_of(m, l * 8)) * COPIES], 1u);
+        for (int l = 0; l < P::PLAIN_LEVELS; ++l) atomicAdd(&mine[(l * RADIX + digit_of(m, l * 8)) * COPIES], 1u);
+#pragma unroll
+        for (int l = 1; l <= P::PAIR_LEVELS; ++l) {
+            // bits [8l-3, 8l+8): digit_l above the top GROUP_BITS bits of digit_{l-1}
+            const uint32_t e = (uint32_t)(m >> (8 * l - P::GROUP_BITS)) & (uint32_t)(RADIX * CHAINS - 1);
+            atomicAdd(&mine_p[((l - 1) * RADIX * CHAINS + e) * PCOPIES], 1u);
+        }
         return m;
     };
     auto mapped_at = [&](uint64_t idx) -> K { return idx == 0 ? (K)0 : map_key<K>(keys[idx - 1], neg, pos); };  // key before idx
@@ -215,31 +276,63 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const K* __restrict_
     if (inv) atomicOr(inversion, 1u);
     __syncthreads();
     // fold the copies: thread j owns (level, digit) pair j (+1024, ...); reading copy (c + j) % COPIES
-    // in step c keeps the lanes of a half-wave on distinct banks
+    // in step c keeps the lanes of a half-wave on distinct banks.  The block's piece lies inside
+    // one position range (hist_range_of), whose table receives the counts.
+    const uint32_t range = hist_range_of(blockIdx.x, gridDim.x);
     for (int j = tid; j < LEVELS * RADIX; j += HIST_THREADS) {
+        const int l = j / RADIX, d = j % RADIX;
         uint32_t c = 0;
+        if (l < P::PLAIN_LEVELS) {
 #pragma unroll 8
-        for (int k = 0; k < COPIES; ++k) c += s_h[j * COPIES + ((k + j) & (COPIES - 1))];
-        if (c) atomicAdd(&hist[j], (unsigned long long)c);
+            for (int k = 0; k < COPIES; ++k) c += s_h[j * COPIES + ((k + j) & (COPIES - 1))];
+        } else {
+            const uint32_t* tab = s_h + P::PAIR_BASE + ((l - 1) * RADIX * CHAINS + d * CHAINS) * PCOPIES;
+#pragma unroll
+            for (int g = 0; g < CHAINS; ++g) {
+                uint32_t cg = 0;
+#pragma unroll
+                for (int k = 0; k < PCOPIES; ++k) cg += tab[g * PCOPIES + k];
+                if (cg) atomicAdd(&hpair[((size_t)l * CHAINS + g) * RADIX + d], (unsigned long long)cg);
+                c += cg;
+            }
+        }
+        if (c) atomicAdd(&hpos[((size_t)l * CHAINS + range) * RADIX + d], (unsigned long long)c);
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// K2: one block of 256 threads.  For every level: exclusive scan over the 256 digit totals
-// (u64) -> bucket start table, and the skip plan.
+// K2: one block of 256 threads.  Digit totals of every level (sum of the range tables), their
+// exclusive scan -> bucket start table, the skip plan, and for every executed level the chain
+// tables: segment bounds, tile counts, ticket order, and each chain's per-digit start
+// (bucket start + the digit's count in the earlier segments).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void scan_kernel(const unsigned long long* __restrict__ hist,
-                                                   uint64_t* __restrict__ base, Plan* plan, uint32_t levels,
-                                                   uint64_t n, uint32_t allow_skip, uint32_t level_lo,
-                                                   uint32_t level_hi, const uint32_t* __restrict__ inversion) {
+struct ScanArgs {
+    const unsigned long long* hpos;   // [levels][CHAINS][256] from K1
+    const unsigned long long* hpair;  // [levels][CHAINS][256] from K1 (level 0 unused)
+    unsigned long long* hist;         // [levels][256] out: digit totals
+    uint64_t* base;                   // [levels][256] out
+    uint64_t* cbase;                  // [levels][CHAINS][256] out
+    LevelChains* chains;              // [levels] out
+    Plan* plan;
+    const uint32_t* inversion;
+    uint64_t n, hist_piece;
+    uint32_t levels, allow_skip, level_lo, level_hi, hist_grid, tile, use_chains;
+};
+
+__global__ __launch_bounds__(256) void scan_kernel(ScanArgs a) {
     __shared__ uint64_t s_scan[RADIX];
     __shared__ uint32_t s_trivial[MAX_LEVELS];
+    __shared__ uint32_t s_mode[MAX_LEVELS], s_skip[MAX_LEVELS];
+    __shared__ uint64_t s_seg[CHAINS + 1];
+    __shared__ uint64_t s_group_start[MAX_LEVELS][CHAINS];  // bucket start of the first digit of each digit group
     const int d = threadIdx.x;
     if (d < MAX_LEVELS) s_trivial[d] = 0;
     __syncthreads();
-    for (uint32_t l = 0; l < levels; ++l) {
-        const uint64_t total = hist[(size_t)l * RADIX + d];
-        if (total == n) s_trivial[l] = 1;
+    for (uint32_t l = 0; l < a.levels; ++l) {
+        uint64_t total = 0;
+        for (int r = 0; r < CHAINS; ++r) total += a.hpos[((size_t)l * CHAINS + r) * RADIX + d];
+        a.hist[(size_t)l * RADIX + d] = total;
+        if (total == a.n) s_trivial[l] = 1;
         // Hillis-Steele inclusive scan over 256 u64 values
         s_scan[d] = total;
         __syncthreads();
@@ -249,21 +342,68 @@ __global__ __launch_bounds__(256) void scan_kernel(const unsigned long long* __r
             s_scan[d] += y;
             __syncthreads();
         }
-        base[(size_t)l * RADIX + d] = s_scan[d] - total;
+        a.base[(size_t)l * RADIX + d] = s_scan[d] - total;
+        if (d % (RADIX / CHAINS) == 0) s_group_start[l][d / (RADIX / CHAINS)] = s_scan[d] - total;
         __syncthreads();
     }
     if (d == 0) {
         uint32_t in_tmp = 0, executed = 0;
-        const bool already_sorted = allow_skip && *inversion == 0;  // nothing to do at all
+        int prev = -1;  // last executed level
+        const bool already_sorted = a.allow_skip && *a.inversion == 0;  // nothing to do at all
         for (uint32_t l = 0; l < MAX_LEVELS; ++l) {
-            const bool active = l >= level_lo && l < level_hi && l < levels;
-            const bool skip = !active || already_sorted || (allow_skip && s_trivial[l]);
-            plan->skip[l] = skip ? 1u : 0u;
-            plan->src_is_tmp[l] = in_tmp;
-            if (!skip) { in_tmp ^= 1u; ++executed; }
+            const bool active = l >= a.level_lo && l < a.level_hi && l < a.levels;
+            const bool skip = !active || already_sorted || (a.allow_skip && s_trivial[l]);
+            a.plan->skip[l] = s_skip[l] = skip ? 1u : 0u;
+            a.plan->src_is_tmp[l] = in_tmp;
+            uint32_t mode = CHAIN_ONE;
+            if (!skip && a.use_chains) {
+                if (prev < 0) mode = CHAIN_POS;  // reads the array K1 counted, in K1's order
+                else if (prev == (int)l - 1 && a.hpair) mode = CHAIN_PAIR;
+            }
+            a.plan->chain_mode[l] = s_mode[l] = mode;
+            if (!skip) { in_tmp ^= 1u; ++executed; prev = (int)l; }
         }
-        plan->result_in_tmp = in_tmp;
-        plan->executed = executed;
+        a.plan->result_in_tmp = in_tmp;
+        a.plan->executed = executed;
+    }
+    __syncthreads();
+    for (uint32_t l = 0; l < a.levels; ++l) {
+        if (s_skip[l]) continue;  // uniform
+        const uint32_t mode = s_mode[l];
+        LevelChains* lc = a.chains + l;
+        if (d <= CHAINS) {
+            uint64_t lo;
+            if (d == CHAINS) lo = a.n;
+            else if (mode == CHAIN_POS) lo = (uint64_t)hist_first_block((uint32_t)d, a.hist_grid) * a.hist_piece;
+            else if (mode == CHAIN_PAIR) lo = s_group_start[l - 1][d];
+            else lo = d == 0 ? 0 : a.n;
+            s_seg[d] = lo < a.n ? lo : a.n;
+        }
+        __syncthreads();
+        if (d == 0) {
+            uint32_t row = 0;
+            for (int c = 0; c < CHAINS; ++c) {
+                const uint64_t lo = s_seg[c], hi = s_seg[c + 1];
+                lc->seg_lo[c] = lo;
+                const uint32_t nt = hi > lo ? (uint32_t)((hi - (lo & ~(uint64_t)(TILE_ALIGN - 1)) + a.tile - 1) / a.tile) : 0u;
+                lc->ntiles[c] = nt;
+                lc->row0[c] = row;
+                row += nt;
+            }
+            lc->seg_lo[CHAINS] = s_seg[CHAINS];
+            lc->total_tiles = row;
+        }
+        // chain c's first destination of digit d
+        uint64_t acc = a.base[(size_t)l * RADIX + d];
+        for (int c = 0; c < CHAINS; ++c) {
+            a.cbase[((size_t)l * CHAINS + c) * RADIX + d] = acc;
+            uint64_t cnt;
+            if (mode == CHAIN_POS) cnt = a.hpos[((size_t)l * CHAINS + c) * RADIX + d];
+            else if (mode == CHAIN_PAIR) cnt = a.hpair[((size_t)l * CHAINS + c) * RADIX + d];
+            else cnt = c == 0 ? a.hist[(size_t)l * RADIX + d] : 0;
+            acc += cnt;
+        }
+        __syncthreads();
     }
 }
 
@@ -312,7 +452,7 @@ template <typename S>
 __device__ __forceinline__ bool lookback_walk(const S* __restrict__ status, uint32_t t, int tid, const uint32_t* err,
                                               uint64_t& excl
 #ifdef RDST_EXPERIMENTS
-                                              , int level
+                                              , int level, uint32_t stat_row
 #endif
 ) {
     constexpr int SSHIFT = StatusWord<S>::SHIFT;
@@ -360,7 +500,7 @@ __device__ __forceinline__ bool lookback_walk(const S* __restrict__ status, uint
     }
 #ifdef RDST_EXPERIMENTS
     if (tid == 0 && g_exp_stats && level == 0) {  // digit 0's walker, one record per row, no atomics
-        uint32_t* rec = g_exp_stats + (size_t)t * 4;
+        uint32_t* rec = g_exp_stats + (size_t)stat_row * 4;
         rec[0] = lb_iters;
         rec[1] = spins;
         rec[2] = (uint32_t)((int64_t)t - 1 - prev);
@@ -372,19 +512,22 @@ __device__ __forceinline__ bool lookback_walk(const S* __restrict__ status, uint
 
 // registers are capped so that the LDS-limited number of blocks per CU (3 at 32 KiB of staging,
 // more below) is not cut further by VGPRs: second launch-bound argument = waves per SIMD
-constexpr int blocks_per_cu(int nwaves, int stage_bytes) {
-    const int lds = nwaves * 1024 + 2048 + 64 + stage_bytes;
+constexpr int pass_lds_bytes(int nwaves, int delta_bytes, int stage_bytes) {  // wave tables, per-digit deltas, misc, staging
+    return nwaves * 1024 + RADIX * delta_bytes + 80 + stage_bytes;
+}
+constexpr int blocks_per_cu(int nwaves, int delta_bytes, int stage_bytes) {
+    const int lds = pass_lds_bytes(nwaves, delta_bytes, stage_bytes);
     int b = 160 * 1024 / lds;
     if (b * nwaves > 32) b = 32 / nwaves;
     if (b > 3) b = 3;  // beyond three the register budget (<= 64) costs more than it buys
     return b < 1 ? 1 : b;
 }
 template <typename K, typename S, int KPT, int NWAVES, int STAGES, bool MAPPED, bool NARROW>
-__global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NWAVES * 64 * KPT * (int)sizeof(K) / STAGES) * NWAVES + 3) / 4) void onesweep_kernel(
+__global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8, NWAVES * 64 * KPT * (int)sizeof(K) / STAGES) * NWAVES + 3) / 4) void onesweep_kernel(
     K* __restrict__ buf_keys, K* __restrict__ buf_tmp, uint64_t n, int level,
-    const uint64_t* __restrict__ base /* [256] of this level */, S* __restrict__ status /* [tiles][256] of this level */,
-    uint32_t* __restrict__ ticket /* of this level */, const Plan* __restrict__ plan, uint32_t* __restrict__ err,
-    K neg, K pos, uint32_t ablate) {
+    const uint64_t* __restrict__ cbase /* [CHAINS][256] of this level */, S* __restrict__ status /* [rows][256] of this level */,
+    const LevelChains* __restrict__ chains /* of this level */, uint32_t* __restrict__ ticket /* [CHAINS] of this level */,
+    const Plan* __restrict__ plan, uint32_t* __restrict__ err, K neg, K pos, uint32_t ablate) {
     // `ablate` is always 0 in the product build; tools/ builds with -DRDST_EXPERIMENTS can switch
     // stages off to price them (results are then wrong by design, stores stay in range).
 #ifdef RDST_EXPERIMENTS
@@ -410,25 +553,62 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NWAVES * 64 * K
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* wave_hist = reinterpret_cast<uint32_t*>(smem);                          // [NWAVES][256]
-    D* s_delta = reinterpret_cast<D*>(smem + NWAVES * 1024);                          // [256]
-    uint32_t* s_misc = reinterpret_cast<uint32_t*>(smem + NWAVES * 1024 + 2048);      // [16]
-    K* s_keys = reinterpret_cast<K*>(smem + NWAVES * 1024 + 2048 + 64);               // [STAGE_KEYS]
+    constexpr int DELTA_BYTES = RADIX * (int)sizeof(D);
+    D* s_delta = reinterpret_cast<D*>(smem + NWAVES * 1024);                                   // [256]
+    uint32_t* s_misc = reinterpret_cast<uint32_t*>(smem + NWAVES * 1024 + DELTA_BYTES);        // [16]
+    uint64_t* s_begin = reinterpret_cast<uint64_t*>(smem + NWAVES * 1024 + DELTA_BYTES + 64);  // [2]
+    K* s_keys = reinterpret_cast<K*>(smem + NWAVES * 1024 + DELTA_BYTES + 80);                 // [STAGE_KEYS]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int shift = level * 8;
     const int bit0 = shift & 31;
 
+    // Block b takes a tile of chain b % CHAINS — blocks b and b + 8 share an XCD, so a chain's status
+    // rows and its 256 scatter frontiers stay with one XCD's CUs — in ticket order, so a tile's
+    // predecessors have always started; when that chain is handed out it tries the next ones
+    // (segments of a skewed pass differ in length).  The grid has at least one block per tile.
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) {
-        s_misc[0] = RDST_ABL(4) ? blockIdx.x : atomicAdd(ticket, 1u);
+        // the chain's table entries are requested before the ticket, so that only arithmetic
+        // follows the atomic's round trip
+        uint32_t c = blockIdx.x % CHAINS, t = ~0u, valid = 0, row0 = 0;
+        uint64_t begin = 0;
+#pragma unroll 1
+        for (int tries = 0; tries < CHAINS; ++tries) {
+            {
+                const uint32_t nt = chains->ntiles[c];
+                const uint64_t lo = chains->seg_lo[c], hi = chains->seg_lo[c + 1];
+                row0 = chains->row0[c];
+                const uint32_t k = nt ? atomicAdd(ticket + c, 1u) : 0u;
+                if (k < nt) {
+                    t = k;
+                    // every tile but a chain's first starts on a multiple of TILE_ALIGN keys
+                    const uint64_t a0 = lo & ~(uint64_t)(TILE_ALIGN - 1);
+                    begin = t == 0 ? lo : a0 + (uint64_t)t * TILE;
+                    const uint64_t end = a0 + (uint64_t)(t + 1) * TILE < hi ? a0 + (uint64_t)(t + 1) * TILE : hi;
+                    valid = (uint32_t)(end - begin);
+                    break;
+                }
+            }
+            c = (c + 1) % CHAINS;
+        }
+        s_misc[0] = t;
         s_misc[1] = 0;  // block-wide failure flag
+        s_misc[2] = c;
+        s_misc[3] = row0;
+        s_begin[0] = begin;
+        s_begin[1] = valid;
     }
     __syncthreads();
-    const uint32_t t = s_misc[0];
-    const uint64_t tile_begin = (uint64_t)t * TILE;
-    if (tile_begin >= n) return;
-    const uint32_t valid = (n - tile_begin < (uint64_t)TILE) ? (uint32_t)(n - tile_begin) : (uint32_t)TILE;
+    const uint32_t t = s_misc[0];  // tile index inside its chain
+    if (t == ~0u) return;          // every chain is handed out
+    const uint32_t chain = s_misc[2];
+    const uint32_t valid = (uint32_t)s_begin[1];
+    const uint64_t tile_begin = s_begin[0];
     const bool full = valid == (uint32_t)TILE;
-    S* row = status + (size_t)t * RADIX;
+    const uint32_t chain_row0 = s_misc[3];
+    S* const cstatus = status + (size_t)chain_row0 * RADIX;  // the chain's rows
+    S* row = cstatus + (size_t)t * RADIX;
+    const uint64_t* __restrict__ base = cbase + (size_t)chain * RADIX;
 
     // 1. load, wave-striped: lane l of wave w takes keys w*64*KPT + i*64 + l (256 contiguous
     //    bytes per wave-instruction for 4-byte keys), so index order == (wave, i, lane) order.
@@ -564,9 +744,9 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NWAVES * 64 * K
         uint64_t excl = 0;
         bool fail = false;
         if (t > 0 && !RDST_ABL(0)) {
-            fail = !lookback_walk<S>(status, t, tid, err, excl
+            fail = !lookback_walk<S>(cstatus, t, tid, err, excl
 #ifdef RDST_EXPERIMENTS
-                                     , level
+                                     , level, chain_row0 + t
 #endif
             );
             if (!fail) st_relaxed<S>(&row[tid], ((S)ST_INCL << SSHIFT) | ((S)(excl + pub) & SMASK));
@@ -599,17 +779,20 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NWAVES * 64 * K
             __syncthreads();
         }
         // slots of this stage in sub-batches (fewer live registers than one batch of SPT)
-        constexpr int SUB = SPT % 6 == 0 ? 6 : (SPT % 4 == 0 ? 4 : SPT);
+        constexpr int SUB = SPT % 6 == 0 ? 6 : (SPT % 4 == 0 ? 4 : (SPT < 6 ? SPT : 6));  // the last batch may be shorter
 #pragma unroll
         for (int i0 = 0; i0 < SPT; i0 += SUB) {
             K kk[SUB];
             D dd[SUB];
 #pragma unroll
-            for (int i = 0; i < SUB; ++i) kk[i] = s_keys[tid + (i0 + i) * BLOCK];
+            for (int i = 0; i < SUB; ++i)
+                if (i0 + i < SPT) kk[i] = s_keys[tid + (i0 + i) * BLOCK];
 #pragma unroll
-            for (int i = 0; i < SUB; ++i) dd[i] = s_delta[digit_of(kk[i], shift)];
+            for (int i = 0; i < SUB; ++i)
+                if (i0 + i < SPT) dd[i] = s_delta[digit_of(kk[i], shift)];
 #pragma unroll
             for (int i = 0; i < SUB; ++i) {
+                if (i0 + i >= SPT) continue;
                 const uint32_t p = (uint32_t)(stage * STAGE_KEYS) + (uint32_t)tid + (uint32_t)(i0 + i) * BLOCK;  // slot in the tile
                 K out = kk[i];
                 if constexpr (MAPPED) out = unmap_key<K>(out, neg, pos);
@@ -707,13 +890,15 @@ constexpr PassCfg kPassCfgs[] = {
     {8, 24, 12, 2},   // 1: 512 threads, 12288 / 6144 keys per tile, staged in two halves (24 KiB)
     {12, 24, 12, 2},  // 2: 768 threads, 18432 / 9216 keys per tile, two halves (36 KiB)   <- default, 4-byte keys
     {12, 28, 14, 2},  // 3: 768 threads, 21504 / 10752 keys per tile, two halves (42 KiB)  <- default, 8-byte keys
+    {12, 22, 11, 1},  // 4: 768 threads, 16896 / 8448 keys per tile, whole tile staged (66 KiB; two blocks per CU only with 32-bit deltas)
+    {14, 18, 9, 1},   // 5: 896 threads, 16128 / 8064 keys per tile, whole tile staged (63 KiB)
 };
 constexpr int kNumPassCfgs = sizeof(kPassCfgs) / sizeof(kPassCfgs[0]);
 constexpr int default_cfg(uint32_t elem_bytes) { return elem_bytes == 8 ? 3 : 2; }
 // keys per thread for a key width, from the table's 8-byte figure: same bytes per thread
 constexpr int kpt_for(int kpt8, size_t elem_bytes) { return elem_bytes <= 4 ? kpt8 * 2 : (elem_bytes == 8 ? kpt8 : (kpt8 / 2) & ~1); }
 
-struct Tuning { int pass_cfg = -1; int hist_bpc = 0; bool profiling = false; };  // pass_cfg < 0: default_cfg()
+struct Tuning { int pass_cfg = -1; int hist_bpc = 0; bool profiling = false; bool chains = true; };  // pass_cfg < 0: default_cfg()
 uint32_t g_ablate = 0;  // only ever set by the RDST_EXPERIMENTS build
 #ifdef RDST_EXPERIMENTS
 size_t g_exp_lds_total = 0;
@@ -742,7 +927,8 @@ DeviceState g_dev[16];
 struct Layout {
     uint32_t levels, tile, status_bytes;  // status_bytes: 4 or 8 per word
     uint64_t tiles;
-    size_t off_err, off_tickets, off_plan, off_hist, off_status, zero_bytes, off_base, total;
+    size_t off_err, off_tickets, off_plan, off_hpos, off_hpair, off_status, zero_bytes, off_hist, off_base, off_cbase,
+        off_chains, total;
 };
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -756,17 +942,20 @@ Layout make_layout(uint64_t n, uint32_t elem_bytes, uint32_t levels, int cfg) {
     Layout L{};
     L.levels = levels;
     L.tile = (uint32_t)tile_keys(cfg, elem_bytes);
-    L.tiles = (n + L.tile - 1) / L.tile;
-    if (L.tiles == 0) L.tiles = 1;
+    L.tiles = n / L.tile + CHAINS + 2;  // status rows per level: every chain may end and begin on partial tiles
     L.status_bytes = n < (1ull << 30) ? 4 : 8;  // an inclusive prefix can reach n
     size_t o = 0;
     L.off_err = o; o += 64;  // error word + (experiments build) look-back statistics
-    L.off_tickets = o; o += sizeof(uint32_t) * MAX_LEVELS;
+    L.off_tickets = o; o += sizeof(uint32_t) * MAX_LEVELS * CHAINS;
     L.off_plan = o; o += align_up(sizeof(Plan), 16);
-    L.off_hist = o; o += sizeof(uint64_t) * (size_t)levels * RADIX;
+    L.off_hpos = o; o += sizeof(uint64_t) * (size_t)levels * CHAINS * RADIX;
+    L.off_hpair = o; o += sizeof(uint64_t) * (size_t)levels * CHAINS * RADIX;
     L.off_status = o; o += (size_t)L.status_bytes * levels * L.tiles * RADIX;
-    L.zero_bytes = align_up(o, 16); o = L.zero_bytes;
+    L.zero_bytes = align_up(o, 16); o = L.zero_bytes;  // everything up to here is cleared per sort
+    L.off_hist = o; o += sizeof(uint64_t) * (size_t)levels * RADIX;
     L.off_base = o; o += sizeof(uint64_t) * (size_t)levels * RADIX;
+    L.off_cbase = o; o += sizeof(uint64_t) * (size_t)levels * CHAINS * RADIX;
+    L.off_chains = o; o += sizeof(LevelChains) * (size_t)levels;
     L.total = align_up(o, 256);
     return L;
 }
@@ -844,86 +1033,93 @@ KeyMap key_map_for(rdst_key_kind kind, uint32_t elem_bytes) {
     }
 }
 
-template <typename K, int LEVELS, int VEC>
-int launch_hist_v(const K* keys, uint64_t n, uint32_t blocks, KeyMap km, unsigned long long* hist, uint32_t* inversion,
-                  hipStream_t s) {
-    constexpr size_t lds = (size_t)LEVELS * RADIX * (LEVELS <= 4 ? 32 : (LEVELS <= 8 ? 16 : 8)) * sizeof(uint32_t);
+template <typename K, int LEVELS, int VEC, bool PAIR>
+int launch_hist_v(const K* keys, uint64_t n, uint32_t blocks, KeyMap km, unsigned long long* hpos, unsigned long long* hpair,
+                  uint32_t* inversion, hipStream_t s, uint64_t* piece_out) {
+    *piece_out = hist_piece(n, blocks, (uint64_t)HIST_THREADS * VEC * 4);
+    constexpr size_t lds = (size_t)HistPlan<LEVELS, PAIR>::WORDS * sizeof(uint32_t);
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&hist_kernel<K, LEVELS, VEC>),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&hist_kernel<K, LEVELS, VEC, PAIR>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((hist_kernel<K, LEVELS, VEC>), dim3(blocks), dim3(HIST_THREADS), lds, s, keys, n, (K)km.neg,
-                       (K)km.pos, hist, inversion);
+    hipLaunchKernelGGL((hist_kernel<K, LEVELS, VEC, PAIR>), dim3(blocks), dim3(HIST_THREADS), lds, s, keys, n, (K)km.neg,
+                       (K)km.pos, hpos, hpair, inversion);
     HIP_TRY(hipGetLastError());
     return RDST_OK;
 }
 
+// pair == true also fills the joint tables the chain split of the later passes needs
 template <typename K, int LEVELS>
-int launch_hist(const K* keys, uint64_t n, uint32_t blocks, KeyMap km, unsigned long long* hist, uint32_t* inversion,
-                hipStream_t s) {
+int launch_hist(const K* keys, uint64_t n, uint32_t blocks, KeyMap km, unsigned long long* hpos, unsigned long long* hpair,
+                bool pair, uint32_t* inversion, hipStream_t s, uint64_t* piece_out) {
     const bool aligned = (reinterpret_cast<uintptr_t>(keys) & 15u) == 0;
-    if (aligned) return launch_hist_v<K, LEVELS, 16 / sizeof(K)>(keys, n, blocks, km, hist, inversion, s);
-    return launch_hist_v<K, LEVELS, 1>(keys, n, blocks, km, hist, inversion, s);
+    constexpr int V = 16 / sizeof(K);
+    if constexpr (LEVELS >= 2) {
+        if (pair) {
+            if (aligned) return launch_hist_v<K, LEVELS, V, true>(keys, n, blocks, km, hpos, hpair, inversion, s, piece_out);
+            return launch_hist_v<K, LEVELS, 1, true>(keys, n, blocks, km, hpos, hpair, inversion, s, piece_out);
+        }
+    }
+    if (aligned) return launch_hist_v<K, LEVELS, V, false>(keys, n, blocks, km, hpos, hpair, inversion, s, piece_out);
+    return launch_hist_v<K, LEVELS, 1, false>(keys, n, blocks, km, hpos, hpair, inversion, s, piece_out);
 }
 
 template <typename K, typename S, int KPT, int NWAVES, int STAGES, bool MAPPED, bool NARROW>
-int launch_pass_t(K* keys, K* tmp, uint64_t n, int level, const Layout& L, char* ws, KeyMap km, hipStream_t s) {
+int launch_pass_t(K* keys, K* tmp, uint64_t n, int level, const Layout& L, char* ws, KeyMap km, int cus, hipStream_t s) {
     constexpr int TILE = NWAVES * 64 * KPT;
-    size_t lds = (size_t)NWAVES * 1024 + 2048 + 64 + sizeof(K) * (TILE / STAGES);
+    size_t lds = (size_t)pass_lds_bytes(NWAVES, NARROW ? 4 : 8, (int)sizeof(K) * (TILE / STAGES));
+    auto kernel = &onesweep_kernel<K, S, KPT, NWAVES, STAGES, MAPPED, NARROW>;
+    static size_t attr_lds = 0;
 #ifdef RDST_EXPERIMENTS
     if (g_exp_lds_total > lds) lds = g_exp_lds_total;  // fewer blocks per CU
-    static size_t attr_lds = 0;
-    const bool attr_set = attr_lds == lds;
-    attr_lds = lds;
-#else
-    static bool attr_set = false;
 #endif
-    if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&onesweep_kernel<K, S, KPT, NWAVES, STAGES, MAPPED, NARROW>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-#ifndef RDST_EXPERIMENTS
-        attr_set = true;
-#endif
+    if (attr_lds != lds) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_lds = lds;
     }
-    const uint64_t* base = reinterpret_cast<const uint64_t*>(ws + L.off_base) + (size_t)level * RADIX;
+    const uint64_t* cbase = reinterpret_cast<const uint64_t*>(ws + L.off_cbase) + (size_t)level * CHAINS * RADIX;
     S* status = reinterpret_cast<S*>(ws + L.off_status) + (size_t)level * L.tiles * RADIX;
-    uint32_t* ticket = reinterpret_cast<uint32_t*>(ws + L.off_tickets) + level;
+    const LevelChains* chains = reinterpret_cast<const LevelChains*>(ws + L.off_chains) + level;
+    uint32_t* ticket = reinterpret_cast<uint32_t*>(ws + L.off_tickets) + (size_t)level * CHAINS;
     const Plan* plan = reinterpret_cast<const Plan*>(ws + L.off_plan);
     uint32_t* err = reinterpret_cast<uint32_t*>(ws + L.off_err);
-    const dim3 grid((uint32_t)L.tiles), block(NWAVES * 64);
+    (void)cus;
+    const dim3 grid((uint32_t)L.tiles), block(NWAVES * 64);  // >= one block per tile of any chain split
     hipLaunchKernelGGL((onesweep_kernel<K, S, KPT, NWAVES, STAGES, MAPPED, NARROW>), grid, block, lds, s, keys, tmp, n,
-                       level, base, status, ticket, plan, err, (K)km.neg, (K)km.pos, g_ablate);
+                       level, cbase, status, chains, ticket, plan, err, (K)km.neg, (K)km.pos, g_ablate);
     HIP_TRY(hipGetLastError());
     return RDST_OK;
 }
 
 template <typename K, typename S, bool MAPPED, bool NARROW>
-int launch_pass_s(int cfg, K* keys, K* tmp, uint64_t n, int level, const Layout& L, char* ws, KeyMap km, hipStream_t s) {
+int launch_pass_s(int cfg, K* keys, K* tmp, uint64_t n, int level, const Layout& L, char* ws, KeyMap km, int cus, hipStream_t s) {
     switch (cfg) {
-        case 0: return launch_pass_t<K, S, kpt_for(8, sizeof(K)), 8, 1, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, s);
-        case 1: return launch_pass_t<K, S, kpt_for(12, sizeof(K)), 8, 2, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, s);
-        case 2: return launch_pass_t<K, S, kpt_for(12, sizeof(K)), 12, 2, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, s);
-        case 3: return launch_pass_t<K, S, kpt_for(14, sizeof(K)), 12, 2, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, s);
+        case 0: return launch_pass_t<K, S, kpt_for(8, sizeof(K)), 8, 1, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, cus, s);
+        case 1: return launch_pass_t<K, S, kpt_for(12, sizeof(K)), 8, 2, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, cus, s);
+        case 2: return launch_pass_t<K, S, kpt_for(12, sizeof(K)), 12, 2, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, cus, s);
+        case 3: return launch_pass_t<K, S, kpt_for(14, sizeof(K)), 12, 2, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, cus, s);
+        case 4: return launch_pass_t<K, S, kpt_for(11, sizeof(K)), 12, 1, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, cus, s);
+        case 5: return launch_pass_t<K, S, kpt_for(9, sizeof(K)), 14, 1, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, cus, s);
     }
     return fail(RDST_ERR_ARG, "bad pass config");
 }
 
 template <typename K>
-int launch_pass(int cfg, K* keys, K* tmp, uint64_t n, int level, const Layout& L, char* ws, KeyMap km, hipStream_t s) {
+int launch_pass(int cfg, K* keys, K* tmp, uint64_t n, int level, const Layout& L, char* ws, KeyMap km, int cus, hipStream_t s) {
     const bool mapped = km.neg != 0 || km.pos != 0;
     const bool narrow = n * sizeof(K) < (1ull << 32);
     if (L.status_bytes == 4) {
         if (narrow) {
-            return mapped ? launch_pass_s<K, uint32_t, true, true>(cfg, keys, tmp, n, level, L, ws, km, s)
-                          : launch_pass_s<K, uint32_t, false, true>(cfg, keys, tmp, n, level, L, ws, km, s);
+            return mapped ? launch_pass_s<K, uint32_t, true, true>(cfg, keys, tmp, n, level, L, ws, km, cus, s)
+                          : launch_pass_s<K, uint32_t, false, true>(cfg, keys, tmp, n, level, L, ws, km, cus, s);
         }
-        return mapped ? launch_pass_s<K, uint32_t, true, false>(cfg, keys, tmp, n, level, L, ws, km, s)
-                      : launch_pass_s<K, uint32_t, false, false>(cfg, keys, tmp, n, level, L, ws, km, s);
+        return mapped ? launch_pass_s<K, uint32_t, true, false>(cfg, keys, tmp, n, level, L, ws, km, cus, s)
+                      : launch_pass_s<K, uint32_t, false, false>(cfg, keys, tmp, n, level, L, ws, km, cus, s);
     }
-    return mapped ? launch_pass_s<K, unsigned long long, true, false>(cfg, keys, tmp, n, level, L, ws, km, s)
-                  : launch_pass_s<K, unsigned long long, false, false>(cfg, keys, tmp, n, level, L, ws, km, s);
+    return mapped ? launch_pass_s<K, unsigned long long, true, false>(cfg, keys, tmp, n, level, L, ws, km, cus, s)
+                  : launch_pass_s<K, unsigned long long, false, false>(cfg, keys, tmp, n, level, L, ws, km, cus, s);
 }
 
 // The whole device-side pipeline for levels [level_lo, level_hi): memset, K1, K2, passes,
@@ -961,18 +1157,38 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     const uint64_t max_useful = (n + per_block_min - 1) / per_block_min;
     if (blocks > max_useful) blocks = max_useful;
     if (blocks < 1) blocks = 1;
-    unsigned long long* hist = reinterpret_cast<unsigned long long*>(ws + L.off_hist);
+    unsigned long long* hpos = reinterpret_cast<unsigned long long*>(ws + L.off_hpos);
     uint32_t* inversion = reinterpret_cast<uint32_t*>(ws + L.off_err) + 1;  // second word of the (cleared) header
-    rc = launch_hist<K, LEVELS>(keys, n, (uint32_t)blocks, km, hist, inversion, s);
+    uint64_t piece = 0;
+    // the joint tables pay off only when a second pass can follow a first
+    const bool pair = g_tuning.chains && LEVELS >= 2 && level_hi > level_lo + 1;
+    unsigned long long* hpair = reinterpret_cast<unsigned long long*>(ws + L.off_hpair);
+    rc = launch_hist<K, LEVELS>(keys, n, (uint32_t)blocks, km, hpos, hpair, pair, inversion, s, &piece);
     if (rc) return rc;
     if ((rc = prof_mark(*D, s))) return rc;
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(256), 0, s, hist, reinterpret_cast<uint64_t*>(ws + L.off_base),
-                       reinterpret_cast<Plan*>(ws + L.off_plan), (uint32_t)LEVELS, n, allow_skip ? 1u : 0u, level_lo,
-                       level_hi, inversion);
+    ScanArgs sa{};
+    sa.hpos = hpos;
+    sa.hpair = pair ? hpair : nullptr;
+    sa.hist = reinterpret_cast<unsigned long long*>(ws + L.off_hist);
+    sa.base = reinterpret_cast<uint64_t*>(ws + L.off_base);
+    sa.cbase = reinterpret_cast<uint64_t*>(ws + L.off_cbase);
+    sa.chains = reinterpret_cast<LevelChains*>(ws + L.off_chains);
+    sa.plan = reinterpret_cast<Plan*>(ws + L.off_plan);
+    sa.inversion = inversion;
+    sa.n = n;
+    sa.hist_piece = piece;
+    sa.levels = (uint32_t)LEVELS;
+    sa.allow_skip = allow_skip ? 1u : 0u;
+    sa.level_lo = level_lo;
+    sa.level_hi = level_hi;
+    sa.hist_grid = (uint32_t)blocks;
+    sa.tile = L.tile;
+    sa.use_chains = g_tuning.chains ? 1u : 0u;
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(256), 0, s, sa);
     HIP_TRY(hipGetLastError());
     if ((rc = prof_mark(*D, s))) return rc;
     for (uint32_t level = level_lo; level < level_hi; ++level) {
-        rc = launch_pass<K>(cfg, keys, tmp, n, (int)level, L, ws, km, s);
+        rc = launch_pass<K>(cfg, keys, tmp, n, (int)level, L, ws, km, D->cus, s);
         if (rc) return rc;
         if ((rc = prof_mark(*D, s))) return rc;
     }
@@ -1046,6 +1262,12 @@ int rdst_hip_set_tuning(int pass_config, int hist_blocks_per_cu) {
     if (pass_config >= kNumPassCfgs) return fail(RDST_ERR_ARG, "tuning value out of range");
     g_tuning.pass_cfg = pass_config >= 0 ? pass_config : -1;
     g_tuning.hist_bpc = hist_blocks_per_cu > 0 ? hist_blocks_per_cu : 0;
+    return RDST_OK;
+}
+
+int rdst_hip_set_chain_split(int enabled) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    g_tuning.chains = enabled != 0;
     return RDST_OK;
 }
 

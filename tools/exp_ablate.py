@@ -24,14 +24,15 @@ def main():
         e0.record(); keys.copy_(src); e1.record(); torch.cuda.synchronize()
     print('device copy of the same array (4 GB read + 4 GB write): %.3f ms' % e0.elapsed_time(e1), flush=True)
     lds_list = [int(x) for x in os.environ.get("RDST_EXP_LDS", "0").split(",")]
+    split = os.environ.get("RDST_EXP_SPLIT", "1") != "0"
     for cfg, lds_total in [(c, l) for c in [int(x) for x in os.environ.get("RDST_EXP_CFGS", "0,1,2,3").split(",")] for l in lds_list]:
-        rdst_amd.set_tuning(cfg, 0)
+        rdst_amd.set_tuning(cfg, 0, chain_split=split)
         lib.rdst_hip_exp_set_lds(ctypes.c_uint32(lds_total))
         print(f"-- cfg {cfg} dynamic LDS forced to >= {lds_total} B", flush=True)
         for mask, name in names.items():
             lib.rdst_hip_exp_set_ablation(ctypes.c_uint32(mask))
             tile = {0: 8192, 1: 12288, 2: 18432, 3: 21504}[cfg]
-            stats_tiles = (n + tile - 1) // tile if not (mask & 1) else 0
+            stats_tiles = n // tile + 10 if not (mask & 1) else 0
             if stats_tiles:
                 lib.rdst_hip_exp_stats(None, ctypes.c_uint64(stats_tiles))
             rdst_amd.set_profiling(True)
@@ -50,7 +51,7 @@ def main():
                 import numpy as np
                 rec = np.zeros((stats_tiles, 4), dtype=np.uint32)
                 lib.rdst_hip_exp_stats(rec.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), ctypes.c_uint64(stats_tiles))
-                r = rec[1:]  # tile 0 has no walk
+                r = rec[rec[:, 0] > 0]  # a chain's first tile has no walk
                 lb = (f" | LB(digit 0): windows mean {r[:,0].mean():.1f} p50 {np.median(r[:,0]):.0f} p99 {np.percentile(r[:,0],99):.0f}; "
                       f"blocked polls mean {r[:,1].mean():.1f}; tiles walked mean {r[:,2].mean():.1f} p99 {np.percentile(r[:,2],99):.0f}; "
                       f"clocks mean {r[:,3].mean():.0f} p50 {np.median(r[:,3]):.0f} p99 {np.percentile(r[:,3],99):.0f}")
