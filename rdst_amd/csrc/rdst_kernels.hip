@@ -119,6 +119,10 @@ template <typename S>
 __device__ __forceinline__ void st_relaxed(S* p, S v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+template <typename S>
+__device__ __forceinline__ void st_near(S* p, S v) {  // stays (dirty) in this XCD's L2
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
 // value held by lane - 1 (lane 0: unspecified), as a DPP wave shift: no LDS traffic
 template <typename K>
@@ -449,8 +453,8 @@ __device__ __forceinline__ uint32_t digit_word(K mapped, int shift) {  // 32-bit
 // the whole pass (each round trip crosses the fabric), so RDST_LB_WINDOW predecessor words are
 // fetched at once and then consumed in order.  Bounded: returns false if a word stays EMPTY.
 template <typename S>
-__device__ __forceinline__ bool lookback_walk(const S* __restrict__ status, uint32_t t, int tid, const uint32_t* err,
-                                              uint64_t& excl
+__device__ __forceinline__ bool lookback_walk(const S* __restrict__ status, const S* __restrict__ near_rows, uint32_t t, int tid,
+                                              const uint32_t* err, uint64_t& excl
 #ifdef RDST_EXPERIMENTS
                                               , int level, uint32_t stat_row
 #endif
@@ -461,6 +465,11 @@ __device__ __forceinline__ bool lookback_walk(const S* __restrict__ status, uint
     int64_t prev = (int64_t)t - 1;  // next row whose word is still to be consumed
     uint32_t spins = 0;
     bool done = false;
+    // `near_rows` is the copy of the rows kept in the writer's L2 (plain stores): a walker on the
+    // writer's XCD — the normal case, a chain stays with one XCD — is served from that L2.  A word
+    // seen EMPTY there is either not written yet or was written on another XCD (whose L2 this
+    // one never sees): from then on the walk reads the write-through copy, which every XCD sees.
+    const S* rows = near_rows;
 #ifdef RDST_EXPERIMENTS
     const uint64_t lb_t0 = __builtin_amdgcn_s_memtime();
     uint32_t lb_iters = 0;
@@ -474,7 +483,7 @@ __device__ __forceinline__ bool lookback_walk(const S* __restrict__ status, uint
         for (int k = 0; k < LB_WINDOW; ++k) {
             const int64_t idx = prev - k;
             // row 0 is always INCLUSIVE, so an index below 0 is never consumed
-            v[k] = idx >= 0 ? ld_relaxed<S>(status + (size_t)idx * RADIX + tid) : ((S)ST_INCL << SSHIFT);
+            v[k] = idx >= 0 ? ld_relaxed<S>(rows + (size_t)idx * RADIX + tid) : ((S)ST_INCL << SSHIFT);
         }
         bool blocked = false;
         int consumed = 0;
@@ -493,6 +502,7 @@ __device__ __forceinline__ bool lookback_walk(const S* __restrict__ status, uint
         }
         prev -= consumed;
         if (blocked && !done) {
+            if (rows != status) { rows = status; continue; }  // no wait before the first look at the far copy
             __builtin_amdgcn_s_sleep(2);
             ++spins;
             if (spins > SPIN_LIMIT || ((spins & 255u) == 0 && ld_relaxed<uint32_t>(err) != 0)) return false;
@@ -526,6 +536,7 @@ template <typename K, typename S, int KPT, int NWAVES, int STAGES, bool MAPPED, 
 __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8, NWAVES * 64 * KPT * (int)sizeof(K) / STAGES) * NWAVES + 3) / 4) void onesweep_kernel(
     K* __restrict__ buf_keys, K* __restrict__ buf_tmp, uint64_t n, int level,
     const uint64_t* __restrict__ cbase /* [CHAINS][256] of this level */, S* __restrict__ status /* [rows][256] of this level */,
+    S* __restrict__ status_near /* same shape: the copy that stays in the writer's L2 */,
     const LevelChains* __restrict__ chains /* of this level */, uint32_t* __restrict__ ticket /* [CHAINS] of this level */,
     const Plan* __restrict__ plan, uint32_t* __restrict__ err, K neg, K pos, uint32_t ablate) {
     // `ablate` is always 0 in the product build; tools/ builds with -DRDST_EXPERIMENTS can switch
@@ -607,7 +618,9 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8,
     const bool full = valid == (uint32_t)TILE;
     const uint32_t chain_row0 = s_misc[3];
     S* const cstatus = status + (size_t)chain_row0 * RADIX;  // the chain's rows
+    S* const cstatus_near = status_near + (size_t)chain_row0 * RADIX;
     S* row = cstatus + (size_t)t * RADIX;
+    S* row_near = cstatus_near + (size_t)t * RADIX;
     const uint64_t* __restrict__ base = cbase + (size_t)chain * RADIX;
 
     // 1. load, wave-striped: lane l of wave w takes keys w*64*KPT + i*64 + l (256 contiguous
@@ -679,7 +692,9 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8,
         }
         pub = count_d;
         if (tid == RADIX - 1) pub -= (uint32_t)TILE - valid;  // sentinels are not keys
-        st_relaxed<S>(&row[tid], ((S)(t == 0 ? ST_INCL : ST_AGG) << SSHIFT) | (S)pub);
+        const S word = ((S)(t == 0 ? ST_INCL : ST_AGG) << SSHIFT) | (S)pub;
+        st_near<S>(&row_near[tid], word);
+        st_relaxed<S>(&row[tid], word);
     }
 
     // 4. exclusive scan of the 256 digit counts -> start of each digit's run inside the tile
@@ -744,12 +759,16 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8,
         uint64_t excl = 0;
         bool fail = false;
         if (t > 0 && !RDST_ABL(0)) {
-            fail = !lookback_walk<S>(cstatus, t, tid, err, excl
+            fail = !lookback_walk<S>(cstatus, cstatus_near, t, tid, err, excl
 #ifdef RDST_EXPERIMENTS
                                      , level, chain_row0 + t
 #endif
             );
-            if (!fail) st_relaxed<S>(&row[tid], ((S)ST_INCL << SSHIFT) | ((S)(excl + pub) & SMASK));
+            if (!fail) {
+                const S word = ((S)ST_INCL << SSHIFT) | ((S)(excl + pub) & SMASK);
+                st_near<S>(&row_near[tid], word);
+                st_relaxed<S>(&row[tid], word);
+            }
         }
         if (fail) {
             atomicOr(err, ERR_LOOKBACK_TIMEOUT);
@@ -888,13 +907,18 @@ struct PassCfg { int nwaves, kpt4, kpt8, stages; };
 constexpr PassCfg kPassCfgs[] = {
     {8, 16, 8, 1},    // 0: 512 threads,  8192 / 4096 keys per tile, whole tile staged in LDS (32 KiB)
     {8, 24, 12, 2},   // 1: 512 threads, 12288 / 6144 keys per tile, staged in two halves (24 KiB)
-    {12, 24, 12, 2},  // 2: 768 threads, 18432 / 9216 keys per tile, two halves (36 KiB)   <- default, 4-byte keys
+    {12, 24, 12, 2},  // 2: 768 threads, 18432 / 9216 keys per tile, two halves (36 KiB)   <- default, 4-byte keys from 4 GiB up, 16-byte keys
     {12, 28, 14, 2},  // 3: 768 threads, 21504 / 10752 keys per tile, two halves (42 KiB)  <- default, 8-byte keys
-    {12, 22, 11, 1},  // 4: 768 threads, 16896 / 8448 keys per tile, whole tile staged (66 KiB; two blocks per CU only with 32-bit deltas)
-    {14, 18, 9, 1},   // 5: 896 threads, 16128 / 8064 keys per tile, whole tile staged (63 KiB)
+    {12, 22, 11, 1},  // 4: 768 threads, 16896 / 8448 keys per tile, whole tile staged (66 KiB; two blocks per CU only with 32-bit deltas)  <- default, keys up to 4 bytes below 4 GiB
 };
 constexpr int kNumPassCfgs = sizeof(kPassCfgs) / sizeof(kPassCfgs[0]);
-constexpr int default_cfg(uint32_t elem_bytes) { return elem_bytes == 8 ? 3 : 2; }
+// 4-byte and narrower keys: the whole tile staged once (config 4) while two blocks still fit a CU,
+// i.e. while destinations are 32-bit offsets (n * size < 4 GiB); otherwise the two-stage shapes
+constexpr int default_cfg(uint32_t elem_bytes, uint64_t n) {
+    if (elem_bytes == 8) return 3;
+    if (elem_bytes <= 4 && n * elem_bytes < (1ull << 32)) return 4;
+    return 2;
+}
 // keys per thread for a key width, from the table's 8-byte figure: same bytes per thread
 constexpr int kpt_for(int kpt8, size_t elem_bytes) { return elem_bytes <= 4 ? kpt8 * 2 : (elem_bytes == 8 ? kpt8 : (kpt8 / 2) & ~1); }
 
@@ -927,7 +951,7 @@ DeviceState g_dev[16];
 struct Layout {
     uint32_t levels, tile, status_bytes;  // status_bytes: 4 or 8 per word
     uint64_t tiles;
-    size_t off_err, off_tickets, off_plan, off_hpos, off_hpair, off_status, zero_bytes, off_hist, off_base, off_cbase,
+    size_t off_err, off_tickets, off_plan, off_hpos, off_hpair, off_status, off_status_near, zero_bytes, off_hist, off_base, off_cbase,
         off_chains, total;
 };
 
@@ -951,6 +975,7 @@ Layout make_layout(uint64_t n, uint32_t elem_bytes, uint32_t levels, int cfg) {
     L.off_hpos = o; o += sizeof(uint64_t) * (size_t)levels * CHAINS * RADIX;
     L.off_hpair = o; o += sizeof(uint64_t) * (size_t)levels * CHAINS * RADIX;
     L.off_status = o; o += (size_t)L.status_bytes * levels * L.tiles * RADIX;
+    L.off_status_near = o; o += (size_t)L.status_bytes * levels * L.tiles * RADIX;
     L.zero_bytes = align_up(o, 16); o = L.zero_bytes;  // everything up to here is cleared per sort
     L.off_hist = o; o += sizeof(uint64_t) * (size_t)levels * RADIX;
     L.off_base = o; o += sizeof(uint64_t) * (size_t)levels * RADIX;
@@ -1081,6 +1106,7 @@ int launch_pass_t(K* keys, K* tmp, uint64_t n, int level, const Layout& L, char*
     }
     const uint64_t* cbase = reinterpret_cast<const uint64_t*>(ws + L.off_cbase) + (size_t)level * CHAINS * RADIX;
     S* status = reinterpret_cast<S*>(ws + L.off_status) + (size_t)level * L.tiles * RADIX;
+    S* status_near = reinterpret_cast<S*>(ws + L.off_status_near) + (size_t)level * L.tiles * RADIX;
     const LevelChains* chains = reinterpret_cast<const LevelChains*>(ws + L.off_chains) + level;
     uint32_t* ticket = reinterpret_cast<uint32_t*>(ws + L.off_tickets) + (size_t)level * CHAINS;
     const Plan* plan = reinterpret_cast<const Plan*>(ws + L.off_plan);
@@ -1088,7 +1114,7 @@ int launch_pass_t(K* keys, K* tmp, uint64_t n, int level, const Layout& L, char*
     (void)cus;
     const dim3 grid((uint32_t)L.tiles), block(NWAVES * 64);  // >= one block per tile of any chain split
     hipLaunchKernelGGL((onesweep_kernel<K, S, KPT, NWAVES, STAGES, MAPPED, NARROW>), grid, block, lds, s, keys, tmp, n,
-                       level, cbase, status, chains, ticket, plan, err, (K)km.neg, (K)km.pos, g_ablate);
+                       level, cbase, status, status_near, chains, ticket, plan, err, (K)km.neg, (K)km.pos, g_ablate);
     HIP_TRY(hipGetLastError());
     return RDST_OK;
 }
@@ -1101,7 +1127,6 @@ int launch_pass_s(int cfg, K* keys, K* tmp, uint64_t n, int level, const Layout&
         case 2: return launch_pass_t<K, S, kpt_for(12, sizeof(K)), 12, 2, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, cus, s);
         case 3: return launch_pass_t<K, S, kpt_for(14, sizeof(K)), 12, 2, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, cus, s);
         case 4: return launch_pass_t<K, S, kpt_for(11, sizeof(K)), 12, 1, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, cus, s);
-        case 5: return launch_pass_t<K, S, kpt_for(9, sizeof(K)), 14, 1, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, cus, s);
     }
     return fail(RDST_ERR_ARG, "bad pass config");
 }
@@ -1132,7 +1157,7 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     int rc = current_device_state(&D);
     if (rc) return rc;
     int cfg = g_tuning.pass_cfg;
-    if (cfg < 0 || cfg >= kNumPassCfgs) cfg = default_cfg(sizeof(K));
+    if (cfg < 0 || cfg >= kNumPassCfgs) cfg = default_cfg(sizeof(K), n);
     const Layout L = make_layout(n, sizeof(K), LEVELS, cfg);
     if (L.tiles >= (1ull << 31)) return fail(RDST_ERR_ARG, "len too large for one launch");
     rc = ensure_workspace(*D, L.total);
@@ -1148,7 +1173,10 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     if (g_tuning.profiling) D->prof_runs.push_back({D->prof_used, 0});
     if ((rc = prof_mark(*D, s))) return rc;
     HIP_TRY(hipMemsetAsync(ws, 0, L.off_status, s));
-    if (status_hi > status_lo) HIP_TRY(hipMemsetAsync(ws + status_lo, 0, status_hi - status_lo, s));
+    if (status_hi > status_lo) {
+        HIP_TRY(hipMemsetAsync(ws + status_lo, 0, status_hi - status_lo, s));
+        HIP_TRY(hipMemsetAsync(ws + status_lo + (L.off_status_near - L.off_status), 0, status_hi - status_lo, s));
+    }
     if ((rc = prof_mark(*D, s))) return rc;
 
     // K1: one 128-KiB-LDS block per CU (more only on request), but no more than the data needs
@@ -1331,7 +1359,7 @@ int rdst_hip_profile_run(int run, float* out_ms, uint32_t capacity, uint32_t* n_
 uint64_t rdst_hip_workspace_bytes(uint64_t len, uint32_t elem_bytes) {
     if (elem_bytes != 1 && elem_bytes != 2 && elem_bytes != 4 && elem_bytes != 8 && elem_bytes != 16) return 0;
     int cfg = g_tuning.pass_cfg;
-    if (cfg < 0 || cfg >= kNumPassCfgs) cfg = default_cfg(elem_bytes);
+    if (cfg < 0 || cfg >= kNumPassCfgs) cfg = default_cfg(elem_bytes, len);
     return make_layout(len, elem_bytes, elem_bytes, cfg).total;
 }
 

@@ -52,9 +52,9 @@ def test_host_entry_point_sorts_numpy_in_place(gpu, oracle):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_sort_matches_oracle_over_sizes(gpu, oracle, dtype):
-    tile = 18432 if np.dtype(dtype).itemsize == 4 else 10752
-    sizes = [0, 1, 2, 3, 10, 100, 127, 128, 129, 5_000, tile - 1, tile, tile + 1, 2 * tile - 1, 2 * tile + 1, 50_000,
-             100_000, 300_000, 1_000_003, 5_000_011]
+    tile = 16896 if np.dtype(dtype).itemsize == 4 else 10752  # default tile of the key width
+    sizes = [0, 1, 2, 3, 10, 100, 127, 128, 129, 5_000, tile - 1, tile, tile + 1, 2 * tile - 1, 2 * tile + 1, 18432, 50_000,
+             100_000, 8 * tile, 8 * tile + 31, 300_000, 1_000_003, 5_000_011]
     for i, n in enumerate(sizes):
         a = random_bits(n, dtype, seed=100 + i).copy()
         exp = a.copy()
@@ -62,6 +62,39 @@ def test_sort_matches_oracle_over_sizes(gpu, oracle, dtype):
         got = _device_sort(gpu, a)
         assert same_bits(got, exp), (dtype, n)
         assert same_bits(exp, reference_sorted(a))  # oracle vs independent numpy, same input
+
+
+@pytest.mark.parametrize("dtype", ["uint32", "uint64", "float32"])
+def test_chain_split_shapes(gpu, dtype):
+    """Every pass splits its source into 8 segments with a look-back chain each (position ranges for
+    the first pass, groups of the previous digit afterwards, one chain after a skipped level).
+    Inputs that bend that: a skipped middle level, previous digits crowded into one group or
+    missing from most, segments shorter than a tile — each sorted with the split on and off and
+    against numpy on the mapped keys."""
+    u = np.dtype({"float32": "uint32"}.get(dtype, dtype))
+    bits = u.itemsize * 8
+    rng = np.random.default_rng(77)
+    n = 2_000_003
+    full = rng.integers(0, 1 << 63, size=n, dtype=np.uint64).astype(u) if bits == 32 else rng.integers(0, 1 << 64, size=n, dtype=np.uint64)
+    cases = {
+        "level 1 constant": (full & ~u.type(0xFF00)) | u.type(0x4200),
+        "level 0 in one group": (full & ~u.type(0xE0)),
+        "level 0 90% in group 7": np.where(rng.random(n) < 0.9, full | u.type(0xE0), full),
+        "level 1 only two digits": (full & ~u.type(0xFE00)),
+        "levels 0-1 constant": (full & ~u.type(0xFFFF)) | u.type(0x1234),
+        "top levels only": full & (u.type(0xFF) << u.type(bits - 8)),
+        "short": full[:40_000],
+        "tiny": full[:700],
+    }
+    try:
+        for name, a in cases.items():
+            a = np.ascontiguousarray(a).view(dtype)
+            exp = reference_sorted(a)
+            for split in (True, False):
+                gpu.set_tuning(chain_split=split)
+                assert same_bits(_device_sort(gpu, a), exp), (dtype, name, split)
+    finally:
+        gpu.set_tuning()
 
 
 @pytest.mark.parametrize("dtype", SMALL_DTYPES)
