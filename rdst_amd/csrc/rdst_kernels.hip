@@ -228,18 +228,30 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const K* __restrict_
 #else
     bool inv = true;  // A/B build without the test: never claim "sorted"
 #endif
-    auto count = [&](K raw, K before) -> K {
+    auto count = [&](K raw, K before, bool careful) -> K {
         const K m = map_key<K>(raw, neg, pos);
 #ifndef RDST_NO_SORTED_CHECK
         inv |= before > m;
 #endif
 #pragma unroll
-        for (int l = 0; l < P::PLAIN_LEVELS; ++l) atomicAdd(&mine[(l * RADIX + digit_of(m, l * 8)) * COPIES], 1u);
+        for (int l = 0; l < P::PLAIN_LEVELS; ++l) {
+            uint32_t* w = &mine[(l * RADIX + digit_of(m, l * 8)) * COPIES];
+            if (PAIR || !careful) atomicAdd(w, 1u);
+            else if (COPIES >= 32 || __all((int)(digit_of(m, l * 8) == (uint32_t)__builtin_amdgcn_readfirstlane((int)digit_of(m, l * 8)))) == 0) atomicAdd(w, 1u);
+            else if ((tid & 63) == 0) atomicAdd(w, 64u);
+        }
 #pragma unroll
         for (int l = 1; l <= P::PAIR_LEVELS; ++l) {
             // bits [8l-3, 8l+8): digit_l above the top GROUP_BITS bits of digit_{l-1}
             const uint32_t e = (uint32_t)(m >> (8 * l - P::GROUP_BITS)) & (uint32_t)(RADIX * CHAINS - 1);
-            atomicAdd(&mine_p[((l - 1) * RADIX * CHAINS + e) * PCOPIES], 1u);
+            uint32_t* w = &mine_p[((l - 1) * RADIX * CHAINS + e) * PCOPIES];
+            // sorted or low-entropy input puts a whole wave on one entry, which the few bank columns of
+            // the joint tables would serialise 16 ways and more: one lane adds for the wave then
+            if (careful && __all((int)(e == (uint32_t)__builtin_amdgcn_readfirstlane((int)e))) != 0) {
+                if ((tid & 63) == 0) atomicAdd(w, 64u);
+            } else {
+                atomicAdd(w, 1u);
+            }
         }
         return m;
     };
@@ -248,7 +260,10 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const K* __restrict_
     struct alignas(sizeof(K) * VEC) V { K e[VEC]; };
     uint64_t i = p_begin + (uint64_t)tid * VEC;
     constexpr uint64_t STRIDE = (uint64_t)HIST_THREADS * VEC;
-    for (; i + 3 * STRIDE + VEC <= p_end; i += 4 * STRIDE) {
+    // the batched loop runs while the LAST lane of the wave still has a full batch: whole waves
+    // enter and leave it together (the wave-wide shortcuts below count on all 64 lanes)
+    const uint64_t lane_rest = (uint64_t)(63 - (tid & 63)) * VEC;
+    for (; i + lane_rest + 3 * STRIDE + VEC <= p_end; i += 4 * STRIDE) {
         V v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const V*>(keys + i + u * STRIDE);
@@ -259,23 +274,34 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const K* __restrict_
 #pragma unroll
         for (int u = 0; u < 4; ++u) edge[u] = ((tid & 63) == 0 && i + u * STRIDE > 0) ? keys[i + u * STRIDE - 1] : (K)0;
 #endif
+        // looking for wave-uniform entries costs a few instructions per key and level, so it is done
+        // only for a batch whose first key has wave-uniform upper bits (random keys: never)
+        bool careful = false;
+        if constexpr (LEVELS >= 2) {
+            const uint32_t top = (uint32_t)(map_key<K>(v[0].e[0], neg, pos) >> (8 * (LEVELS - 1)));
+            careful = __all((int)(top == (uint32_t)__builtin_amdgcn_readfirstlane((int)top))) != 0;
+        }
+        auto batch = [&](bool c) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 4; ++u) {
 #ifndef RDST_NO_SORTED_CHECK
-            K before = lane_below<K>(map_key<K>(v[u].e[VEC - 1], neg, pos));
-            if ((tid & 63) == 0) before = (i + u * STRIDE > 0) ? map_key<K>(edge[u], neg, pos) : (K)0;
+                K before = lane_below<K>(map_key<K>(v[u].e[VEC - 1], neg, pos));
+                if ((tid & 63) == 0) before = (i + u * STRIDE > 0) ? map_key<K>(edge[u], neg, pos) : (K)0;
 #else
-            K before = 0;
+                K before = 0;
 #endif
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) before = count(v[u].e[e], before);
-        }
+                for (int e = 0; e < VEC; ++e) before = count(v[u].e[e], before, c);
+            }
+        };
+        if (careful) batch(true);
+        else batch(false);
     }
     for (; i < p_end; i += STRIDE) {  // remainder of the piece, element-wise
         K before = mapped_at(i);
 #pragma unroll
         for (int e = 0; e < VEC; ++e)
-            if (i + e < p_end) before = count(keys[i + e], before);
+            if (i + e < p_end) before = count(keys[i + e], before, false);
     }
     if (inv) atomicOr(inversion, 1u);
     __syncthreads();

@@ -12,6 +12,16 @@ if dt == "u32":
     src = torch.randint(-2**31, 2**31, (n,), dtype=torch.int32, device="cuda", generator=g).view(torch.uint32)
 else:
     src = torch.randint(-2**63, 2**63 - 1, (n,), dtype=torch.int64, device="cuda", generator=g).view(torch.uint64)
+dist = os.environ.get("RDST_DIST", "uniform")
+if dt == "u32" and dist != "uniform":
+    r = src.view(torch.int32)
+    if dist == "bimodal":
+        src = torch.cat([(r[: n // 2] >> 16) & 0xFFFF, r[n // 2:] << 16]).view(torch.uint32)
+    elif dist == "twodigit":
+        src = (r & ~0xFE00).view(torch.uint32)
+    elif dist == "onegroup":
+        src = (r & ~0xE0).view(torch.uint32)
+    del r
 keys = torch.empty_like(src); tmp = torch.empty_like(src)
 ref = None
 cfgs = [int(x) for x in os.environ.get("RDST_CFGS", "-1").split(",")]

@@ -16,7 +16,13 @@ cases = {
     "bimodal (gen_inputs shift 16)": torch.cat([(rnd[: n // 2] >> 16) & 0xFFFF, rnd[n // 2:] << 16]),
     "all equal": torch.full((n,), 1234567, dtype=torch.int32, device="cuda"),
     "256 distinct values": rnd & 0xFF00,
+    "low byte in one digit group (one chain in pass 1)": rnd & ~0xE0,
+    "byte 1 in two digits": rnd & ~0xFE00,
+    "byte 1 constant (skipped level)": (rnd & ~0xFF00) | 0x4200,
+    "gaussian-ish (sum of 4 uniforms)": ((rnd >> 2) + (torch.roll(rnd, 1) >> 2) + (torch.roll(rnd, 2) >> 2) + (torch.roll(rnd, 3) >> 2)),
 }
+if len(sys.argv) > 2:
+    cases = {k: v for k, v in cases.items() if any(w in k for w in sys.argv[2].split(","))}
 tmp = torch.empty(n, dtype=torch.uint32, device="cuda")
 keys = torch.empty(n, dtype=torch.int32, device="cuda")
 for name, src in cases.items():
