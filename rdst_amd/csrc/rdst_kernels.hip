@@ -4,13 +4,15 @@
 // (paths relative to the reference tree):
 //
 //   K1 hist_kernel        one coalesced read of the key slice -> 256-bin histograms of EVERY
-//                         level.                                 get_counts_with_ends
+//                         level, split by position range and by group of the previous digit
+//                         (what the look-back chains of K3 start from).  get_counts_with_ends
 //                         (src/sort_utils.rs:109-180), get_tile_counts (:193-244)
-//   K2 scan_kernel        256-bin exclusive scan per level + the level-skip plan.
+//   K2 scan_kernel        256-bin exclusive scan per level, the level-skip plan, chain tables.
 //                         get_prefix_sums (:10-20), level skipping of lsb_sort_adapter
 //                         (src/sorts/lsb_sort.rs:62-83)
 //   K3 onesweep_kernel    one stable counting-sort pass: wave-ballot ranking, tile prefix by
-//                         chained scan with decoupled look-back. out_of_place_sort
+//                         chained scan with decoupled look-back, one chain per source segment
+//                         and XCD.                               out_of_place_sort
 //                         (src/sorts/out_of_place_sort.rs:52-108), mt_lsb_sort (:40-133)
 //   K4 key map            fused into K1/K3 digit extraction.     src/radix_key_impl.rs:3-185
 //   K6 level_counts_kernel single-level histogram + already_sorted flag (parity hook)
@@ -18,11 +20,10 @@
 // Data layout in HBM: keys are a dense array of K (unsigned 1-, 2-, 4-, 8- or 16-byte bit patterns;
 // signed and float keys stay in their raw encoding in memory, the order-preserving map is applied
 // in registers for digit extraction only).  `keys` and `tmp` ping-pong per executed pass.  The workspace
-// holds, per sort: an error word, per-level tile tickets, the plan, histograms u64[L][256],
-// look-back status words (u32 when n < 2^30, else u64) [L][tiles][256], and the bucket start
-// table u64[L][256].  A per-range ("multi-chain") offset table is NOT possible with one
-// up-front histogram: range histograms change with every pass's permutation, only the global
-// ones are permutation-invariant.
+// holds, per sort: an error word, per-level and per-chain tile tickets, the plan, K1's count tables
+// u64[L][8][256] (per position range, and per group of the previous digit), look-back status words
+// (u32 if n < 2^30, else u64) [L][rows][256] in two copies, digit totals and bucket starts
+// u64[L][256], chain starts u64[L][8][256] and the chain tables.
 //
 // Written for wave64 / 256 CUs in 8 XCDs only; no other target is supported.
 
@@ -438,10 +439,11 @@ __global__ __launch_bounds__(256) void scan_kernel(ScanArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// K3: one stable scatter pass.  grid = number of tiles, block = NWAVES*64, one tile of
-// NWAVES*64*KPT keys per block.  Tile ids come from a ticket counter so that a tile's
-// predecessors have always started: forward progress of the look-back does not depend on the
-// order in which the hardware dispatches workgroups, nor on where (which XCD) they land.
+// K3: one stable scatter pass.  grid >= number of tiles, block = NWAVES*64, one tile of
+// NWAVES*64*KPT keys per block.  The source is split into CHAINS segments with a look-back chain
+// each (LevelChains); a block takes the next tile of "its" chain from that chain's ticket counter,
+// so that a tile's predecessors have always started: forward progress of the look-back does not
+// depend on the order in which the hardware dispatches workgroups, nor on where (which XCD) they land.
 // Every cross-workgroup word is an agent-scope relaxed atomic whose value carries its own state
 // bits (no separate flag, hence no fence).
 //   S       status word: u32 while every prefix fits 30 bits (n < 2^30), u64 above
@@ -927,9 +929,9 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
     } while (0)
 
 struct PassCfg { int nwaves, kpt4, kpt8, stages; };
-// Scatter-kernel shapes.  The pass is bound by the look-back walk, whose cost per tile is set
-// by latency, so throughput grows with the keys a resident block holds: the
-// defaults are the largest tiles that neither spill registers nor cost a block per CU.
+// Scatter-kernel shapes.  Larger tiles mean longer runs per digit and fewer look-backs;
+// staging the whole tile at once saves a second pass over the slots.  The defaults are the
+// largest tiles that neither spill registers nor cost a block per CU.
 constexpr PassCfg kPassCfgs[] = {
     {8, 16, 8, 1},    // 0: 512 threads,  8192 / 4096 keys per tile, whole tile staged in LDS (32 KiB)
     {8, 24, 12, 2},   // 1: 512 threads, 12288 / 6144 keys per tile, staged in two halves (24 KiB)
