@@ -81,11 +81,14 @@ struct Plan {
 constexpr int CHAINS = 8;
 constexpr uint32_t CHAIN_ONE = 0, CHAIN_POS = 1, CHAIN_PAIR = 2;
 constexpr uint32_t TILE_ALIGN = 32;  // keys; every tile but a chain's first starts on a multiple
+constexpr int TICKET_STRIDE = 32;    // words: every chain's ticket counter, and the mask word, on a 128-byte line of its own
+constexpr int TICKET_ROW = (CHAINS + 1) * TICKET_STRIDE;  // words per level
 
 struct LevelChains {  // written by K2 for every executed level, read by K3's ticket holder
     uint64_t seg_lo[CHAINS + 1];  // chain c covers source indices [seg_lo[c], seg_lo[c+1])
     uint32_t row0[CHAINS];        // first status row of chain c
     uint32_t ntiles[CHAINS];      // tiles of chain c
+    uint32_t shared[CHAINS];      // chain much longer than the others: blocks of every XCD will end up on it
     uint32_t total_tiles;
     uint32_t pad[3];
 };
@@ -276,11 +279,15 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const K* __restrict_
         for (int u = 0; u < 4; ++u) edge[u] = ((tid & 63) == 0 && i + u * STRIDE > 0) ? keys[i + u * STRIDE - 1] : (K)0;
 #endif
         // looking for wave-uniform entries costs a few instructions per key and level, so it is done
-        // only for a batch whose first key has wave-uniform upper bits (random keys: never)
+        // only for a batch whose first key has one in some level (random keys: never)
         bool careful = false;
         if constexpr (LEVELS >= 2) {
-            const uint32_t top = (uint32_t)(map_key<K>(v[0].e[0], neg, pos) >> (8 * (LEVELS - 1)));
-            careful = __all((int)(top == (uint32_t)__builtin_amdgcn_readfirstlane((int)top))) != 0;
+            const K m0 = map_key<K>(v[0].e[0], neg, pos);
+#pragma unroll
+            for (int l = 1; l < LEVELS; ++l) {
+                const uint32_t e = (uint32_t)(m0 >> (8 * l - 3)) & (uint32_t)(RADIX * CHAINS - 1);
+                careful |= __all((int)(e == (uint32_t)__builtin_amdgcn_readfirstlane((int)e))) != 0;
+            }
         }
         auto batch = [&](bool c) {
 #pragma unroll
@@ -345,6 +352,7 @@ struct ScanArgs {
     uint64_t* cbase;                  // [levels][CHAINS][256] out
     LevelChains* chains;              // [levels] out
     Plan* plan;
+    uint32_t* tickets;                // [levels][TICKET_ROW]: K2 marks the empty chains in the mask word
     const uint32_t* inversion;
     uint64_t n, hist_piece;
     uint32_t levels, allow_skip, level_lo, level_hi, hist_grid, tile, use_chains;
@@ -423,6 +431,14 @@ __global__ __launch_bounds__(256) void scan_kernel(ScanArgs a) {
             }
             lc->seg_lo[CHAINS] = s_seg[CHAINS];
             lc->total_tiles = row;
+            // walkers of such a chain skip the L2-resident copy of the status rows: most of its
+            // tiles are written on other XCDs
+            uint32_t empty = 0;
+            for (int c = 0; c < CHAINS; ++c) {
+                lc->shared[c] = (uint64_t)lc->ntiles[c] * CHAINS * 2 > (uint64_t)row * 3 ? 1u : 0u;
+                if (lc->ntiles[c] == 0) empty |= 1u << c;
+            }
+            a.tickets[(size_t)l * TICKET_ROW + CHAINS * TICKET_STRIDE] = empty;
         }
         // chain c's first destination of digit d
         uint64_t acc = a.base[(size_t)l * RADIX + d];
@@ -467,6 +483,20 @@ __device__ __forceinline__ uint32_t peers_below(uint32_t word, int bit0) {
         same_lo = __builtin_amdgcn_bitop3_b32(same_lo, (uint32_t)bal, (uint32_t)m, 0x90);
         same_hi = __builtin_amdgcn_bitop3_b32(same_hi, (uint32_t)(bal >> 32), (uint32_t)m, 0x90);
     }
+    return __builtin_amdgcn_mbcnt_hi(same_hi, __builtin_amdgcn_mbcnt_lo(same_lo, 0u));
+}
+
+// the same, plus the size of my digit's group in this wave (heavy-digit path)
+__device__ __forceinline__ uint32_t peers_below_total(uint32_t word, int bit0, uint32_t& total) {
+    uint32_t same_lo = ~0u, same_hi = ~0u;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const int m = __builtin_amdgcn_sbfe((int)word, (unsigned)(bit0 + b), 1u);
+        const uint64_t bal = __builtin_amdgcn_ballot_w64(m != 0);
+        same_lo = __builtin_amdgcn_bitop3_b32(same_lo, (uint32_t)bal, (uint32_t)m, 0x90);
+        same_hi = __builtin_amdgcn_bitop3_b32(same_hi, (uint32_t)(bal >> 32), (uint32_t)m, 0x90);
+    }
+    total = (uint32_t)__builtin_popcount(same_lo) + (uint32_t)__builtin_popcount(same_hi);
     return __builtin_amdgcn_mbcnt_hi(same_hi, __builtin_amdgcn_mbcnt_lo(same_lo, 0u));
 }
 
@@ -565,7 +595,7 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8,
     K* __restrict__ buf_keys, K* __restrict__ buf_tmp, uint64_t n, int level,
     const uint64_t* __restrict__ cbase /* [CHAINS][256] of this level */, S* __restrict__ status /* [rows][256] of this level */,
     S* __restrict__ status_near /* same shape: the copy that stays in the writer's L2 */,
-    const LevelChains* __restrict__ chains /* of this level */, uint32_t* __restrict__ ticket /* [CHAINS] of this level */,
+    const LevelChains* __restrict__ chains /* of this level */, uint32_t* __restrict__ ticket /* of this level: [CHAINS + 1][TICKET_STRIDE], per chain, then the mask of chains handed out */,
     const Plan* __restrict__ plan, uint32_t* __restrict__ err, K neg, K pos, uint32_t ablate) {
     // `ablate` is always 0 in the product build; tools/ builds with -DRDST_EXPERIMENTS can switch
     // stages off to price them (results are then wrong by design, stores stay in range).
@@ -607,17 +637,21 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8,
     // (segments of a skewed pass differ in length).  The grid has at least one block per tile.
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) {
-        // the chain's table entries are requested before the ticket, so that only arithmetic
-        // follows the atomic's round trip
+        // The chain's table entries and the mask of chains already handed out are requested before
+        // the ticket, so that only arithmetic follows the atomic's round trip.  A block that finds
+        // a chain dry says so in the mask (word CHAINS of the ticket row): later blocks go straight
+        // to a chain that still has tiles instead of paying an atomic per dry chain.
         uint32_t c = blockIdx.x % CHAINS, t = ~0u, valid = 0, row0 = 0;
         uint64_t begin = 0;
+        const uint32_t dry = ld_relaxed<uint32_t>(ticket + CHAINS * TICKET_STRIDE);
 #pragma unroll 1
         for (int tries = 0; tries < CHAINS; ++tries) {
-            {
+            if (!((dry >> c) & 1u)) {
                 const uint32_t nt = chains->ntiles[c];
                 const uint64_t lo = chains->seg_lo[c], hi = chains->seg_lo[c + 1];
                 row0 = chains->row0[c];
-                const uint32_t k = nt ? atomicAdd(ticket + c, 1u) : 0u;
+                s_misc[8] = chains->shared[c];
+                const uint32_t k = atomicAdd(ticket + c * TICKET_STRIDE, 1u);
                 if (k < nt) {
                     t = k;
                     // every tile but a chain's first starts on a multiple of TILE_ALIGN keys
@@ -627,6 +661,7 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8,
                     valid = (uint32_t)(end - begin);
                     break;
                 }
+                atomicOr(ticket + CHAINS * TICKET_STRIDE, 1u << c);
             }
             c = (c + 1) % CHAINS;
         }
@@ -646,9 +681,9 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8,
     const bool full = valid == (uint32_t)TILE;
     const uint32_t chain_row0 = s_misc[3];
     S* const cstatus = status + (size_t)chain_row0 * RADIX;  // the chain's rows
-    S* const cstatus_near = status_near + (size_t)chain_row0 * RADIX;
+    S* const cstatus_near = (s_misc[8] ? status : status_near) + (size_t)chain_row0 * RADIX;  // what walkers read first
     S* row = cstatus + (size_t)t * RADIX;
-    S* row_near = cstatus_near + (size_t)t * RADIX;
+    S* row_near = status_near + ((size_t)chain_row0 + t) * RADIX;
     const uint64_t* __restrict__ base = cbase + (size_t)chain * RADIX;
 
     // 1. load, wave-striped: lane l of wave w takes keys w*64*KPT + i*64 + l (256 contiguous
@@ -684,14 +719,18 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8,
     uint32_t* wh = wave_hist + wave * RADIX;
 #pragma unroll
     for (int j = 0; j < 4; ++j) wh[lane + 64 * j] = 0;
-    // Sorted or low-entropy input puts all 64 lanes of a round on one bin, which would serialise
-    // the LDS atomic 64 ways: a wave-uniform round is counted (and later ranked) by one lane.
-    // Looking for such rounds costs a few instructions each, so it is only done when the wave's
-    // first round is one (random keys: never).
+    // Sorted or low-entropy input puts many lanes of a round on one bin, which would serialise
+    // the LDS atomics up to 64 ways.  A wave whose first round looks like that — one digit in all
+    // lanes, or many lanes holding their neighbour's digit — takes the careful path: a round with a
+    // single digit is counted (and later ranked) by one lane; in any other round the lanes of a
+    // digit are matched by ballots and its first lane adds the group's size.  Random keys: never.
     uint32_t uniform_rounds = 0;  // bit i: round i holds a single digit (wave-uniform value)
+    bool careful = false;         // wave-uniform
     {
         const uint32_t d0 = digit_of(mk[0], shift);
-        if (__all((int)(d0 == (uint32_t)__builtin_amdgcn_readfirstlane((int)d0))) != 0) {
+        const uint32_t dn = (uint32_t)__builtin_amdgcn_mov_dpp((int)d0, 0x138, 0xf, 0xf, false);  // lane - 1's digit
+        careful = __builtin_popcountll(__builtin_amdgcn_ballot_w64(d0 == dn) & ~1ull) >= 8;
+        if (careful) {
 #pragma unroll
             for (int i = 0; i < KPT; ++i) {
                 const uint32_t d = digit_of(mk[i], shift);
@@ -699,7 +738,9 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8,
                     if (lane == 0) wh[d] += 64u;
                     uniform_rounds |= 1u << i;
                 } else {
-                    atomicAdd(&wh[d], 1u);
+                    uint32_t total;
+                    const uint32_t below = peers_below_total(digit_word<K>(mk[i], shift), bit0, total);
+                    if (below == 0) atomicAdd(&wh[d], total);
                 }
             }
         } else {
@@ -764,6 +805,11 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8,
             below = (uint32_t)lane;
             __builtin_amdgcn_wave_barrier();
             if (lane == 0) *slot = b + 64u;
+        } else if (careful) {              // heavy digits: the group's first lane advances the slot
+            uint32_t total;
+            below = peers_below_total(digit_word<K>(mk[i], shift), bit0, total);
+            __builtin_amdgcn_wave_barrier();
+            if (below == 0) *slot = b + total;
         } else {
             below = RDST_ABL(3) ? 0u : peers_below(digit_word<K>(mk[i], shift), bit0);
             __builtin_amdgcn_wave_barrier();
@@ -998,7 +1044,8 @@ Layout make_layout(uint64_t n, uint32_t elem_bytes, uint32_t levels, int cfg) {
     L.status_bytes = n < (1ull << 30) ? 4 : 8;  // an inclusive prefix can reach n
     size_t o = 0;
     L.off_err = o; o += 64;  // error word + (experiments build) look-back statistics
-    L.off_tickets = o; o += sizeof(uint32_t) * MAX_LEVELS * CHAINS;
+    o = align_up(o, 128);
+    L.off_tickets = o; o += sizeof(uint32_t) * MAX_LEVELS * TICKET_ROW;  // per chain + mask of chains handed out, a line each
     L.off_plan = o; o += align_up(sizeof(Plan), 16);
     L.off_hpos = o; o += sizeof(uint64_t) * (size_t)levels * CHAINS * RADIX;
     L.off_hpair = o; o += sizeof(uint64_t) * (size_t)levels * CHAINS * RADIX;
@@ -1136,7 +1183,7 @@ int launch_pass_t(K* keys, K* tmp, uint64_t n, int level, const Layout& L, char*
     S* status = reinterpret_cast<S*>(ws + L.off_status) + (size_t)level * L.tiles * RADIX;
     S* status_near = reinterpret_cast<S*>(ws + L.off_status_near) + (size_t)level * L.tiles * RADIX;
     const LevelChains* chains = reinterpret_cast<const LevelChains*>(ws + L.off_chains) + level;
-    uint32_t* ticket = reinterpret_cast<uint32_t*>(ws + L.off_tickets) + (size_t)level * CHAINS;
+    uint32_t* ticket = reinterpret_cast<uint32_t*>(ws + L.off_tickets) + (size_t)level * TICKET_ROW;
     const Plan* plan = reinterpret_cast<const Plan*>(ws + L.off_plan);
     uint32_t* err = reinterpret_cast<uint32_t*>(ws + L.off_err);
     (void)cus;
@@ -1230,6 +1277,7 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     sa.cbase = reinterpret_cast<uint64_t*>(ws + L.off_cbase);
     sa.chains = reinterpret_cast<LevelChains*>(ws + L.off_chains);
     sa.plan = reinterpret_cast<Plan*>(ws + L.off_plan);
+    sa.tickets = reinterpret_cast<uint32_t*>(ws + L.off_tickets);
     sa.inversion = inversion;
     sa.n = n;
     sa.hist_piece = piece;
