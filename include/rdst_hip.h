@@ -109,6 +109,19 @@ int rdst_hip_sort(void* host_data, uint64_t len, uint32_t elem_bytes, rdst_key_k
 int rdst_hip_sort_device(void* dev_keys, void* dev_tmp, uint64_t len, uint32_t elem_bytes,
                          rdst_key_kind kind, uint32_t levels, void* stream);
 
+/* Key-value sort, device-resident: sorts `dev_keys` (4- or 8-byte built-in keys) and carries
+ * `dev_vals` (4- or 8-byte payloads, e.g. the index of the record a key came from) along.
+ * the device route for slices of structs whose `RadixKey` is a built-in key
+ * field (benches/struct_sort.rs:11-27, examples/impl_radix_key.rs:32-56) — extract
+ * (key, index), sort the pairs here, gather the records.  The passes are stable, so pairs with
+ * equal keys keep their input order; rdst itself promises no order among them
+ * (src/radix_sort.rs:21-45 "unstable"), so this is one of the outputs rdst may produce.
+ * Both tmp arrays have the size of their originals; asynchronous on `stream` like
+ * rdst_hip_sort_device, failures are reported by rdst_hip_device_status. */
+int rdst_hip_sort_pairs_device(void* dev_keys, void* dev_vals, void* dev_tmp_keys, void* dev_tmp_vals,
+                               uint64_t len, uint32_t key_bytes, rdst_key_kind kind, uint32_t levels,
+                               uint32_t val_bytes, void* stream);
+
 /* Blocks until everything queued on `stream` by this library has finished and returns
  * RDST_ERR_DEVICE if any kernel raised the workspace error word since the last check. */
 int rdst_hip_device_status(void* stream);

@@ -17,6 +17,7 @@ RDST_OK = 0
 SYMBOLS = (
     "rdst_hip_sort",
     "rdst_hip_sort_device",
+    "rdst_hip_sort_pairs_device",
     "rdst_hip_device_status",
     "rdst_hip_level_counts",
     "rdst_hip_all_level_counts",
@@ -74,6 +75,7 @@ def load():
     u64p, u8p = ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint8)
     lib.rdst_hip_sort.argtypes = [vp, u64, u32, ci, u32, ctypes.POINTER(HipOptsC)]
     lib.rdst_hip_sort_device.argtypes = [vp, vp, u64, u32, ci, u32, vp]
+    lib.rdst_hip_sort_pairs_device.argtypes = [vp, vp, vp, vp, u64, u32, ci, u32, u32, vp]
     lib.rdst_hip_device_status.argtypes = [vp]
     lib.rdst_hip_level_counts.argtypes = [vp, u64, u32, ci, u32, u64p, u8p, u8p, u8p, vp]
     lib.rdst_hip_all_level_counts.argtypes = [vp, u64, u32, ci, u32, u64p, vp]

@@ -590,9 +590,14 @@ constexpr int blocks_per_cu(int nwaves, int delta_bytes, int stage_bytes) {
     if (b > 3) b = 3;  // beyond three the register budget (<= 64) costs more than it buys
     return b < 1 ? 1 : b;
 }
-template <typename K, typename S, int KPT, int NWAVES, int STAGES, bool MAPPED, bool NARROW>
-__global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8, NWAVES * 64 * KPT * (int)sizeof(K) / STAGES) * NWAVES + 3) / 4) void onesweep_kernel(
-    K* __restrict__ buf_keys, K* __restrict__ buf_tmp, uint64_t n, int level,
+struct NoVal {};  // keys only
+template <typename V> struct ValBytes { static constexpr int value = (int)sizeof(V); };
+template <> struct ValBytes<NoVal> { static constexpr int value = 0; };
+
+// V: payload carried with every key (key-value sort: 4- or 8-byte values, whole tile staged), or NoVal
+template <typename K, typename S, int KPT, int NWAVES, int STAGES, bool MAPPED, bool NARROW, typename V = NoVal>
+__global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8, NWAVES * 64 * KPT * ((int)sizeof(K) + ValBytes<V>::value) / STAGES) * NWAVES + 3) / 4) void onesweep_kernel(
+    K* __restrict__ buf_keys, K* __restrict__ buf_tmp, V* __restrict__ buf_vals, V* __restrict__ buf_vtmp, uint64_t n, int level,
     const uint64_t* __restrict__ cbase /* [CHAINS][256] of this level */, S* __restrict__ status /* [rows][256] of this level */,
     S* __restrict__ status_near /* same shape: the copy that stays in the writer's L2 */,
     const LevelChains* __restrict__ chains /* of this level */, uint32_t* __restrict__ ticket /* of this level: [CHAINS + 1][TICKET_STRIDE], per chain, then the mask of chains handed out */,
@@ -614,11 +619,15 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8,
     using D = typename std::conditional<NARROW, uint32_t, uint64_t>::type;  // destination offset (bytes if NARROW, else elements)
     static_assert(BLOCK >= RADIX, "need one thread per digit");
     static_assert(KPT % STAGES == 0 && (STAGES == 1 || TILE <= 65536), "stage split / 16-bit slot packing");
+    constexpr bool HAS_V = ValBytes<V>::value != 0;
+    static_assert(!HAS_V || STAGES == 1, "payloads are staged with the whole tile");
 
     if (plan->skip[level]) return;
     const bool from_tmp = plan->src_is_tmp[level] != 0;
     const K* __restrict__ src = from_tmp ? buf_tmp : buf_keys;
     K* __restrict__ dst = from_tmp ? buf_keys : buf_tmp;
+    const V* __restrict__ vsrc = from_tmp ? buf_vtmp : buf_vals;
+    V* __restrict__ vdst = from_tmp ? buf_vals : buf_vtmp;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* wave_hist = reinterpret_cast<uint32_t*>(smem);                          // [NWAVES][256]
@@ -627,6 +636,7 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8,
     uint32_t* s_misc = reinterpret_cast<uint32_t*>(smem + NWAVES * 1024 + DELTA_BYTES);        // [16]
     uint64_t* s_begin = reinterpret_cast<uint64_t*>(smem + NWAVES * 1024 + DELTA_BYTES + 64);  // [2]
     K* s_keys = reinterpret_cast<K*>(smem + NWAVES * 1024 + DELTA_BYTES + 80);                 // [STAGE_KEYS]
+    V* s_vals = reinterpret_cast<V*>(smem + NWAVES * 1024 + DELTA_BYTES + 80 + sizeof(K) * STAGE_KEYS);  // [STAGE_KEYS] (HAS_V)
 
     const int shift = level * 8;
     const int bit0 = shift & 31;
@@ -689,9 +699,18 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8,
     // 1. load, wave-striped: lane l of wave w takes keys w*64*KPT + i*64 + l (256 contiguous
     //    bytes per wave-instruction for 4-byte keys), so index order == (wave, i, lane) order.
     K mk[KPT];
+    V mv[HAS_V ? KPT : 1];
     {
         const K* tsrc = src + tile_begin;
         const uint32_t wbase = (uint32_t)wave * 64u * KPT + (uint32_t)lane;
+        if constexpr (HAS_V) {
+            const V* tv = vsrc + tile_begin;
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                const uint32_t idx = wbase + i * 64;
+                if (full || idx < valid) mv[i] = tv[idx];
+            }
+        }
         if (full) {
 #pragma unroll
             for (int i = 0; i < KPT; ++i) mk[i] = tsrc[wbase + i * 64];
@@ -817,6 +836,7 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8,
         }
         if constexpr (STAGES == 1) {
             s_keys[b + below] = mk[i];
+            if constexpr (HAS_V) s_vals[b + below] = mv[i];
         } else {
             uint32_t sl = b + below;
             // pin the slot here: its inputs are eight ballots (SGPR pairs); left alone the
@@ -877,9 +897,15 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8,
         for (int i0 = 0; i0 < SPT; i0 += SUB) {
             K kk[SUB];
             D dd[SUB];
+            V vv[HAS_V ? SUB : 1];
 #pragma unroll
             for (int i = 0; i < SUB; ++i)
                 if (i0 + i < SPT) kk[i] = s_keys[tid + (i0 + i) * BLOCK];
+            if constexpr (HAS_V) {
+#pragma unroll
+                for (int i = 0; i < SUB; ++i)
+                    if (i0 + i < SPT) vv[i] = s_vals[tid + (i0 + i) * BLOCK];
+            }
 #pragma unroll
             for (int i = 0; i < SUB; ++i)
                 if (i0 + i < SPT) dd[i] = s_delta[digit_of(kk[i], shift)];
@@ -898,12 +924,21 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8,
                     const uint32_t g = dd[i] + p * (uint32_t)sizeof(K);  // byte offset, < 2^32
                     const bool ok = g < (uint32_t)n * (uint32_t)sizeof(K);
                     bad |= !ok && (full || p < valid);
-                    if (ok && (full || p < valid)) *reinterpret_cast<K*>(reinterpret_cast<unsigned char*>(dst) + g) = out;
+                    if (ok && (full || p < valid)) {
+                        *reinterpret_cast<K*>(reinterpret_cast<unsigned char*>(dst) + g) = out;
+                        if constexpr (HAS_V) {  // same element index, in the value array's stride
+                            const uint32_t gv = sizeof(V) == sizeof(K) ? g : (sizeof(V) > sizeof(K) ? g * (uint32_t)(sizeof(V) / sizeof(K)) : g / (uint32_t)(sizeof(K) / sizeof(V)));
+                            *reinterpret_cast<V*>(reinterpret_cast<unsigned char*>(vdst) + gv) = vv[i];
+                        }
+                    }
                 } else {
                     const uint64_t g = dd[i] + p;
                     const bool ok = g < n;
                     bad |= !ok && (full || p < valid);
-                    if (ok && (full || p < valid)) dst[g] = out;
+                    if (ok && (full || p < valid)) {
+                        dst[g] = out;
+                        if constexpr (HAS_V) vdst[g] = vv[i];
+                    }
                 }
             }
         }
@@ -1036,10 +1071,10 @@ int tile_keys(int cfg, uint32_t elem_bytes) {
     return p.nwaves * 64 * kpt_for(p.kpt8, elem_bytes);
 }
 
-Layout make_layout(uint64_t n, uint32_t elem_bytes, uint32_t levels, int cfg) {
+Layout make_layout(uint64_t n, uint32_t elem_bytes, uint32_t levels, int cfg, uint32_t tile_override = 0) {
     Layout L{};
     L.levels = levels;
-    L.tile = (uint32_t)tile_keys(cfg, elem_bytes);
+    L.tile = tile_override ? tile_override : (uint32_t)tile_keys(cfg, elem_bytes);
     L.tiles = n / L.tile + CHAINS + 2;  // status rows per level: every chain may end and begin on partial tiles
     L.status_bytes = n < (1ull << 30) ? 4 : 8;  // an inclusive prefix can reach n
     size_t o = 0;
@@ -1166,11 +1201,12 @@ int launch_hist(const K* keys, uint64_t n, uint32_t blocks, KeyMap km, unsigned 
     return launch_hist_v<K, LEVELS, 1, false>(keys, n, blocks, km, hpos, hpair, inversion, s, piece_out);
 }
 
-template <typename K, typename S, int KPT, int NWAVES, int STAGES, bool MAPPED, bool NARROW>
-int launch_pass_t(K* keys, K* tmp, uint64_t n, int level, const Layout& L, char* ws, KeyMap km, int cus, hipStream_t s) {
+template <typename K, typename S, int KPT, int NWAVES, int STAGES, bool MAPPED, bool NARROW, typename V = NoVal>
+int launch_pass_t(K* keys, K* tmp, uint64_t n, int level, const Layout& L, char* ws, KeyMap km, int cus, hipStream_t s,
+                  V* vals = nullptr, V* vtmp = nullptr) {
     constexpr int TILE = NWAVES * 64 * KPT;
-    size_t lds = (size_t)pass_lds_bytes(NWAVES, NARROW ? 4 : 8, (int)sizeof(K) * (TILE / STAGES));
-    auto kernel = &onesweep_kernel<K, S, KPT, NWAVES, STAGES, MAPPED, NARROW>;
+    size_t lds = (size_t)pass_lds_bytes(NWAVES, NARROW ? 4 : 8, ((int)sizeof(K) + ValBytes<V>::value) * (TILE / STAGES));
+    auto kernel = &onesweep_kernel<K, S, KPT, NWAVES, STAGES, MAPPED, NARROW, V>;
     static size_t attr_lds = 0;
 #ifdef RDST_EXPERIMENTS
     if (g_exp_lds_total > lds) lds = g_exp_lds_total;  // fewer blocks per CU
@@ -1188,7 +1224,7 @@ int launch_pass_t(K* keys, K* tmp, uint64_t n, int level, const Layout& L, char*
     uint32_t* err = reinterpret_cast<uint32_t*>(ws + L.off_err);
     (void)cus;
     const dim3 grid((uint32_t)L.tiles), block(NWAVES * 64);  // >= one block per tile of any chain split
-    hipLaunchKernelGGL((onesweep_kernel<K, S, KPT, NWAVES, STAGES, MAPPED, NARROW>), grid, block, lds, s, keys, tmp, n,
+    hipLaunchKernelGGL((onesweep_kernel<K, S, KPT, NWAVES, STAGES, MAPPED, NARROW, V>), grid, block, lds, s, keys, tmp, vals, vtmp, n,
                        level, cbase, status, status_near, chains, ticket, plan, err, (K)km.neg, (K)km.pos, g_ablate);
     HIP_TRY(hipGetLastError());
     return RDST_OK;
@@ -1222,18 +1258,42 @@ int launch_pass(int cfg, K* keys, K* tmp, uint64_t n, int level, const Layout& L
                   : launch_pass_s<K, unsigned long long, false, false>(cfg, keys, tmp, n, level, L, ws, km, cus, s);
 }
 
+// Key-value passes: one shape, 768 threads, the whole tile of (key, value) pairs staged in LDS.
+constexpr int pair_kpt(size_t key_bytes, size_t val_bytes) { return key_bytes + val_bytes <= 8 ? 11 : (key_bytes + val_bytes <= 12 ? 7 : 5); }
+constexpr int PAIR_WAVES = 12;
+
+template <typename K, typename V>
+int launch_pass_pairs(K* keys, K* tmp, V* vals, V* vtmp, uint64_t n, int level, const Layout& L, char* ws, KeyMap km, int cus,
+                      hipStream_t s) {
+    constexpr int KPT = pair_kpt(sizeof(K), sizeof(V));
+    const bool mapped = km.neg != 0 || km.pos != 0;
+    const bool narrow = n * (sizeof(K) > sizeof(V) ? sizeof(K) : sizeof(V)) < (1ull << 32);
+    if (L.status_bytes == 4) {
+        if (narrow) {
+            return mapped ? launch_pass_t<K, uint32_t, KPT, PAIR_WAVES, 1, true, true, V>(keys, tmp, n, level, L, ws, km, cus, s, vals, vtmp)
+                          : launch_pass_t<K, uint32_t, KPT, PAIR_WAVES, 1, false, true, V>(keys, tmp, n, level, L, ws, km, cus, s, vals, vtmp);
+        }
+        return mapped ? launch_pass_t<K, uint32_t, KPT, PAIR_WAVES, 1, true, false, V>(keys, tmp, n, level, L, ws, km, cus, s, vals, vtmp)
+                      : launch_pass_t<K, uint32_t, KPT, PAIR_WAVES, 1, false, false, V>(keys, tmp, n, level, L, ws, km, cus, s, vals, vtmp);
+    }
+    return mapped ? launch_pass_t<K, unsigned long long, KPT, PAIR_WAVES, 1, true, false, V>(keys, tmp, n, level, L, ws, km, cus, s, vals, vtmp)
+                  : launch_pass_t<K, unsigned long long, KPT, PAIR_WAVES, 1, false, false, V>(keys, tmp, n, level, L, ws, km, cus, s, vals, vtmp);
+}
+
 // The whole device-side pipeline for levels [level_lo, level_hi): memset, K1, K2, passes,
 // optional copy-back.  `allow_skip` turns on level skipping.  With copy_back == false the
 // result stays where the last executed pass put it (scatter hook: exactly one pass keys->tmp).
-template <typename K, int LEVELS>
+template <typename K, int LEVELS, typename V = NoVal>
 int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level_lo, uint32_t level_hi,
-                 bool allow_skip, bool copy_back, hipStream_t s, Layout* layout_out, char** ws_out) {
+                 bool allow_skip, bool copy_back, hipStream_t s, Layout* layout_out, char** ws_out, V* vals = nullptr,
+                 V* vtmp = nullptr) {
+    constexpr bool HAS_V = ValBytes<V>::value != 0;
     DeviceState* D;
     int rc = current_device_state(&D);
     if (rc) return rc;
     int cfg = g_tuning.pass_cfg;
     if (cfg < 0 || cfg >= kNumPassCfgs) cfg = default_cfg(sizeof(K), n);
-    const Layout L = make_layout(n, sizeof(K), LEVELS, cfg);
+    const Layout L = make_layout(n, sizeof(K), LEVELS, cfg, HAS_V ? PAIR_WAVES * 64 * pair_kpt(sizeof(K), ValBytes<V>::value) : 0);
     if (L.tiles >= (1ull << 31)) return fail(RDST_ERR_ARG, "len too large for one launch");
     rc = ensure_workspace(*D, L.total);
     if (rc) return rc;
@@ -1292,7 +1352,8 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     HIP_TRY(hipGetLastError());
     if ((rc = prof_mark(*D, s))) return rc;
     for (uint32_t level = level_lo; level < level_hi; ++level) {
-        rc = launch_pass<K>(cfg, keys, tmp, n, (int)level, L, ws, km, D->cus, s);
+        if constexpr (HAS_V) rc = launch_pass_pairs<K, V>(keys, tmp, vals, vtmp, n, (int)level, L, ws, km, D->cus, s);
+        else rc = launch_pass<K>(cfg, keys, tmp, n, (int)level, L, ws, km, D->cus, s);
         if (rc) return rc;
         if ((rc = prof_mark(*D, s))) return rc;
     }
@@ -1309,6 +1370,18 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
         else
             hipLaunchKernelGGL((copyback_kernel<K, 1>), dim3((uint32_t)cblocks), dim3(256), 0, s, keys, tmp, n, plan);
         HIP_TRY(hipGetLastError());
+        if constexpr (HAS_V) {
+            const bool valigned = ((reinterpret_cast<uintptr_t>(vals) | reinterpret_cast<uintptr_t>(vtmp)) & 15u) == 0;
+            uint64_t vblocks = (n * sizeof(V) / 16 + 255) / 256;
+            if (vblocks > cap) vblocks = cap;
+            if (vblocks < 1) vblocks = 1;
+            constexpr int VVEC = 16 / sizeof(V);
+            if (valigned)
+                hipLaunchKernelGGL((copyback_kernel<V, VVEC>), dim3((uint32_t)vblocks), dim3(256), 0, s, vals, vtmp, n, plan);
+            else
+                hipLaunchKernelGGL((copyback_kernel<V, 1>), dim3((uint32_t)vblocks), dim3(256), 0, s, vals, vtmp, n, plan);
+            HIP_TRY(hipGetLastError());
+        }
         if ((rc = prof_mark(*D, s))) return rc;
     }
     if (layout_out) *layout_out = L;
@@ -1449,6 +1522,33 @@ int rdst_hip_sort_device(void* dev_keys, void* dev_tmp, uint64_t len, uint32_t e
     std::lock_guard<std::mutex> lock(g_mutex);
     hipStream_t s = static_cast<hipStream_t>(stream);
     RDST_BY_WIDTH(elem_bytes, rc = (run_pipeline<K, LV>(static_cast<K*>(dev_keys), static_cast<K*>(dev_tmp), len, kind, 0, LV, true, true, s, nullptr, nullptr)));
+    return rc;
+}
+
+int rdst_hip_sort_pairs_device(void* dev_keys, void* dev_vals, void* dev_tmp_keys, void* dev_tmp_vals, uint64_t len,
+                               uint32_t key_bytes, rdst_key_kind kind, uint32_t levels, uint32_t val_bytes, void* stream) {
+    int rc = check_common(dev_keys, len, key_bytes, kind, levels);
+    if (rc) return rc;
+    if (key_bytes != 4 && key_bytes != 8) return fail(RDST_ERR_UNSUPPORTED, "key-value sorts take 4- or 8-byte keys");
+    if (val_bytes != 4 && val_bytes != 8) return fail(RDST_ERR_UNSUPPORTED, "key-value sorts carry 4- or 8-byte values");
+    if (len <= 1) return RDST_OK;
+    if (!dev_vals || !dev_tmp_keys || !dev_tmp_vals) return fail(RDST_ERR_ARG, "null value / tmp pointer");
+    if (reinterpret_cast<uintptr_t>(dev_tmp_keys) % key_bytes) return fail(RDST_ERR_ALIGN, "tmp key pointer not aligned to the key size");
+    if ((reinterpret_cast<uintptr_t>(dev_vals) | reinterpret_cast<uintptr_t>(dev_tmp_vals)) % val_bytes)
+        return fail(RDST_ERR_ALIGN, "value pointer not aligned to the value size");
+    std::lock_guard<std::mutex> lock(g_mutex);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define RDST_PAIRS(KT, LV, VT)                                                                                          \
+    rc = (run_pipeline<KT, LV, VT>(static_cast<KT*>(dev_keys), static_cast<KT*>(dev_tmp_keys), len, kind, 0, LV, true, true, s, \
+                                   nullptr, nullptr, static_cast<VT*>(dev_vals), static_cast<VT*>(dev_tmp_vals)))
+    if (key_bytes == 4) {
+        if (val_bytes == 4) RDST_PAIRS(uint32_t, 4, uint32_t);
+        else RDST_PAIRS(uint32_t, 4, uint64_t);
+    } else {
+        if (val_bytes == 4) RDST_PAIRS(uint64_t, 8, uint32_t);
+        else RDST_PAIRS(uint64_t, 8, uint64_t);
+    }
+#undef RDST_PAIRS
     return rc;
 }
 

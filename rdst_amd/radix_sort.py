@@ -96,6 +96,54 @@ def sort_device_tensor(keys, tmp=None, check=True, key=None):
             _lib.check(lib.rdst_hip_device_status(s))
 
 
+def sort_pairs_device_tensor(keys, values, tmp_keys=None, tmp_values=None, check=True):
+    """``rdst_hip_sort_pairs_device``: sort the 1-D HIP tensor ``keys`` (4- or 8-byte built-in key type) in place
+    and permute ``values`` (4- or 8-byte elements, same length) with it.  Stable: equal keys keep their
+    input order (rdst promises none, src/radix_sort.rs:21-45)."""
+    import torch
+    if not (keys.is_cuda and values.is_cuda) or keys.device != values.device:
+        raise ValueError("keys and values must live on the same HIP device")
+    if keys.dim() != 1 or values.dim() != 1 or keys.numel() != values.numel():
+        raise ValueError("keys and values must be 1-D tensors of the same length")
+    if not (keys.is_contiguous() and values.is_contiguous()):
+        raise ValueError("keys and values must be contiguous")
+    kind, nbytes, levels = key_info(keys.dtype)
+    vbytes = values.element_size()
+    n = keys.numel()
+    if n <= 1:
+        return
+    tmp_keys = torch.empty_like(keys) if tmp_keys is None else tmp_keys
+    tmp_values = torch.empty_like(values) if tmp_values is None else tmp_values
+    for t, ref in ((tmp_keys, keys), (tmp_values, values)):
+        if t.dtype != ref.dtype or t.numel() < n or not t.is_contiguous() or t.device != ref.device:
+            raise ValueError("tmp tensors must match their originals in dtype, device and length")
+    lib = _lib.load()
+    with torch.cuda.device(keys.device):
+        s = _stream_handle(keys)
+        _lib.check(lib.rdst_hip_sort_pairs_device(ctypes.c_void_p(keys.data_ptr()), ctypes.c_void_p(values.data_ptr()),
+                                                  ctypes.c_void_p(tmp_keys.data_ptr()), ctypes.c_void_p(tmp_values.data_ptr()),
+                                                  n, nbytes, kind, levels, vbytes, s))
+        if check:
+            _lib.check(lib.rdst_hip_device_status(s))
+
+
+def sort_records_by_key(records, key_field):
+    """Device route for a slice of structs whose ``RadixKey`` is one built-in field
+    (benches/struct_sort.rs:11-27, examples/impl_radix_key.rs:32-56): ``records`` is a 2-D
+    HIP tensor (n, fields), ``key_field`` the column holding the key (the tensor's dtype decides the key kind).  Extracts (key, row index), sorts the pairs on
+    the device, gathers the rows; returns the reordered tensor (rows with equal keys keep their order)."""
+    import torch
+    if records.dim() != 2 or not records.is_cuda:
+        raise ValueError("records must be a 2-D HIP tensor (n, fields)")
+    n = records.shape[0]
+    if n <= 1:
+        return records.clone()
+    keys = records[:, key_field].contiguous()
+    idx = torch.arange(n, dtype=torch.int32 if n < 2**31 else torch.int64, device=records.device)
+    sort_pairs_device_tensor(keys, idx)
+    return records.index_select(0, idx.long() if idx.dtype != torch.int64 else idx)
+
+
 def device_status(device=None):
     """Block on the current stream and raise if a kernel reported failure."""
     import torch

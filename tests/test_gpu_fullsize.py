@@ -61,6 +61,22 @@ def test_one_billion_keys(gpu, name, itype_name, seed):
     assert (k[1:] >= k[:-1]).all()
 
 
+def test_half_a_billion_key_value_pairs(gpu):
+    """5·10^8 (u32 key, i32 row index) pairs: keys non-decreasing, every value still names the row its key
+    came from, the values are a permutation, equal keys keep their input order."""
+    import torch
+    n = 500_000_000
+    src = _gen(torch, n, torch.int32, 0x5D570006) & 0x3FFFFFF   # 2^26 distinct keys: every key repeats
+    keys = src.clone()
+    idx = torch.arange(n, dtype=torch.int32, device="cuda")
+    gpu.sort_pairs_device_tensor(keys.view(torch.uint32), idx)
+    assert _is_sorted(torch, keys)                               # non-negative values: signed order == unsigned order
+    assert bool((src[idx.long()] == keys).all())
+    assert int(idx.sum(dtype=torch.int64)) == n * (n - 1) // 2
+    same = keys[1:] == keys[:-1]
+    assert bool((idx[1:][same] > idx[:-1][same]).all())          # stable
+
+
 def test_more_than_2_pow_30_keys_uses_wide_status_words(gpu):
     """n >= 2^30: the look-back prefix no longer fits 30 bits -> 64-bit status words."""
     import torch

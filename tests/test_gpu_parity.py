@@ -97,6 +97,40 @@ def test_chain_split_shapes(gpu, dtype):
         gpu.set_tuning()
 
 
+@pytest.mark.parametrize("dtype", ["uint32", "int32", "float32", "uint64", "int64", "float64"])
+@pytest.mark.parametrize("vdtype", ["int32", "int64"])
+def test_key_value_pairs(gpu, dtype, vdtype):
+    """rdst_hip_sort_pairs_device: keys sorted, values carried; stable, so the whole
+    result is pinned by numpy's stable argsort of the mapped keys (rdst itself promises no order among
+    equal keys: any such output is one it may produce)."""
+    import torch
+    pair = np.dtype(dtype).itemsize + np.dtype(vdtype).itemsize
+    tile = 768 * {8: 11, 12: 7, 16: 5}[pair]
+    rng = np.random.default_rng(4242)
+    for i, n in enumerate((0, 1, 2, 129, tile - 1, tile, tile + 1, 8 * tile + 31, 100_003, 2_000_003)):
+        a = random_bits(n, dtype, seed=700 + i).copy()
+        if i % 2 == 1 and n > 4:  # few distinct keys: long runs of equal keys, where stability shows
+            a = a[rng.integers(0, 7, size=n)].copy()
+        vals = rng.integers(-(2**31), 2**31, size=n).astype(vdtype)
+        order = np.argsort(mapped_key(a), kind="stable")
+        tk, tv = to_device(a), torch.from_numpy(vals).cuda()
+        gpu.sort_pairs_device_tensor(tk, tv)
+        assert same_bits(to_host(tk, a.dtype), a[order]), (dtype, vdtype, n)
+        assert np.array_equal(tv.cpu().numpy(), vals[order]), (dtype, vdtype, n)
+
+
+def test_records_sorted_by_a_key_field(gpu):
+    """A slice of structs with a built-in key field (benches/struct_sort.rs:11-27): rows follow their key."""
+    import torch
+    rng = np.random.default_rng(99)
+    rec = rng.standard_normal((300_007, 5)).astype(np.float32)
+    rec[::1000, 2] = np.float32(-0.0)
+    rec[5::1000, 2] = np.float32("nan")
+    out = gpu.sort_records_by_key(torch.from_numpy(rec).cuda(), 2).cpu().numpy()
+    order = np.argsort(mapped_key(rec[:, 2].copy()), kind="stable")
+    assert np.array_equal(out.view(np.uint32), rec[order].view(np.uint32))
+
+
 @pytest.mark.parametrize("dtype", SMALL_DTYPES)
 def test_narrow_key_types(gpu, oracle, dtype):
     """u8 / u16 / i8 / i16 (src/radix_key_impl.rs:3-19, :87-103): one- and two-level keys."""
