@@ -4,6 +4,7 @@
 // (include/rdst_hip.h) is C++ with the reference's names, argument meaning and error behaviour:
 //
 //   rdst::radix_sort_unstable(v)                        RadixSort::radix_sort_unstable     src/radix_sort.rs:21-45
+//   rdst::radix_sort_unstable_by_field(v, &T::key)      the same on structs keyed by a field benches/struct_sort.rs:11-27
 //   rdst::radix_sort_builder(v).with_*().sort()         RadixSortBuilder                   src/radix_sort_builder.rs:8-158
 //   rdst::RadixKey<T>::LEVELS / kind                    RadixKey for the built-in types    src/radix_key_impl.rs:1-185
 //   rdst::tuner::{Tuner, TuningParams, Algorithm, ...}  pub mod tuner                      src/tuner.rs:1-40, src/tuners/*.rs
@@ -140,6 +141,21 @@ template <typename T> RadixSortBuilder<T> radix_sort_builder(std::vector<T>& v) 
 template <typename T> RadixSortBuilder<T> radix_sort_builder(T* data, std::size_t len) { return RadixSortBuilder<T>(data, len); }
 template <typename T> void radix_sort_unstable(std::vector<T>& v) { radix_sort_builder(v).sort(); }
 template <typename T> void radix_sort_unstable(T* data, std::size_t len) { radix_sort_builder(data, len).sort(); }
+
+// A slice of structs whose key is one built-in field — what `impl RadixKey for LargeStruct` with
+// `get_level` = the field's expresses in the reference (benches/struct_sort.rs:11-27,
+// examples/impl_radix_key.rs:32-56).  Rows with equal keys keep their order.
+template <typename T, typename KeyT>
+void radix_sort_unstable_by_field(T* data, std::size_t len, KeyT T::*field) {
+    static_assert(std::is_trivially_copyable<T>::value, "rows are moved as bytes");
+    static_assert(sizeof(KeyT) == 4 || sizeof(KeyT) == 8, "the device route takes 4- or 8-byte key fields");
+    if (len <= 1) return;
+    const std::size_t offset = static_cast<std::size_t>(reinterpret_cast<const char*>(&(data[0].*field)) - reinterpret_cast<const char*>(&data[0]));
+    const int rc = rdst_hip_sort_records(data, len, sizeof(T), static_cast<std::uint32_t>(offset), sizeof(KeyT), RadixKey<KeyT>::kind, nullptr);
+    if (rc != RDST_OK) throw Error(rc, rdst_hip_last_error());
+}
+template <typename T, typename KeyT>
+void radix_sort_unstable_by_field(std::vector<T>& v, KeyT T::*field) { radix_sort_unstable_by_field(v.data(), v.size(), field); }
 
 }  // namespace rdst
 #endif  // RDST_HPP

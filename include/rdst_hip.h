@@ -109,6 +109,15 @@ int rdst_hip_sort(void* host_data, uint64_t len, uint32_t elem_bytes, rdst_key_k
 int rdst_hip_sort_device(void* dev_keys, void* dev_tmp, uint64_t len, uint32_t elem_bytes,
                          rdst_key_kind kind, uint32_t levels, void* stream);
 
+/* Replaces `radix_sort_unstable` on a host slice of structs whose `RadixKey` reads one built-in
+ * field (benches/struct_sort.rs:11-27: `LargeStruct { sort_key: f32, .. }` with
+ * `get_level` = the field's; examples/impl_radix_key.rs:32-56).  `record_bytes` = size_of::<T>(),
+ * the key is `key_bytes` (4 or 8) at `key_offset`, naturally aligned; rows travel to the device,
+ * (key, row index) pairs are sorted there, the rows gathered and copied back.  Rows with equal
+ * keys keep their input order (rdst promises none).  Blocking; on failure the slice is untouched. */
+int rdst_hip_sort_records(void* host_records, uint64_t len, uint32_t record_bytes, uint32_t key_offset,
+                          uint32_t key_bytes, rdst_key_kind kind, const rdst_hip_opts* opts);
+
 /* Key-value sort, device-resident: sorts `dev_keys` (4- or 8-byte built-in keys) and carries
  * `dev_vals` (4- or 8-byte payloads, e.g. the index of the record a key came from) along.
  * the device route for slices of structs whose `RadixKey` is a built-in key

@@ -25,6 +25,7 @@ from .radix_sort import (  # noqa: F401
     profile_runs,
     sort_device_tensor,
     sort_host_array,
+    sort_host_records,
     sort_pairs_device_tensor,
     sort_records_by_key,
 )
@@ -32,6 +33,6 @@ from ._lib import RdstHipError  # noqa: F401
 
 __all__ = [
     "radix_sort_unstable", "radix_sort_builder", "RadixSortBuilder", "tuner", "RdstHipError",
-    "sort_device_tensor", "sort_host_array", "sort_pairs_device_tensor", "sort_records_by_key", "level_counts", "all_level_counts", "scatter_level",
+    "sort_device_tensor", "sort_host_array", "sort_host_records", "sort_pairs_device_tensor", "sort_records_by_key", "level_counts", "all_level_counts", "scatter_level",
     "device_status", "set_tuning", "set_profiling", "last_profile", "key_info",
 ]

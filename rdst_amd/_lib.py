@@ -18,6 +18,7 @@ SYMBOLS = (
     "rdst_hip_sort",
     "rdst_hip_sort_device",
     "rdst_hip_sort_pairs_device",
+    "rdst_hip_sort_records",
     "rdst_hip_device_status",
     "rdst_hip_level_counts",
     "rdst_hip_all_level_counts",
@@ -76,6 +77,7 @@ def load():
     lib.rdst_hip_sort.argtypes = [vp, u64, u32, ci, u32, ctypes.POINTER(HipOptsC)]
     lib.rdst_hip_sort_device.argtypes = [vp, vp, u64, u32, ci, u32, vp]
     lib.rdst_hip_sort_pairs_device.argtypes = [vp, vp, vp, vp, u64, u32, ci, u32, u32, vp]
+    lib.rdst_hip_sort_records.argtypes = [vp, u64, u32, u32, u32, ci, ctypes.POINTER(HipOptsC)]
     lib.rdst_hip_device_status.argtypes = [vp]
     lib.rdst_hip_level_counts.argtypes = [vp, u64, u32, ci, u32, u64p, u8p, u8p, u8p, vp]
     lib.rdst_hip_all_level_counts.argtypes = [vp, u64, u32, ci, u32, u64p, vp]

@@ -965,6 +965,28 @@ __global__ __launch_bounds__(256) void copyback_kernel(K* __restrict__ keys, con
     }
 }
 
+// Records with a built-in key field: (key, row index) pairs out of the rows, and
+// the rows back in the order of the sorted indices.  UNIT = widest word the row size allows.
+template <typename K, typename I>
+__global__ __launch_bounds__(256) void extract_key_kernel(const unsigned char* __restrict__ rec, uint64_t n, uint32_t rbytes,
+                                                          uint32_t key_off, K* __restrict__ keys, I* __restrict__ idx) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        keys[i] = *reinterpret_cast<const K*>(rec + i * rbytes + key_off);
+        idx[i] = (I)i;
+    }
+}
+template <typename UNIT, typename I>
+__global__ __launch_bounds__(256) void gather_records_kernel(const UNIT* __restrict__ rec, UNIT* __restrict__ out,
+                                                             const I* __restrict__ idx, uint64_t n, uint32_t units) {
+    const uint64_t total = n * units, stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += stride) {
+        const uint64_t i = g / units;
+        const uint32_t w = (uint32_t)(g - i * units);
+        out[g] = rec[(uint64_t)idx[i] * units + w];
+    }
+}
+
 // K6: one level's histogram + "digit sequence has an inversion" flag
 template <typename K>
 __global__ __launch_bounds__(256) void level_counts_kernel(const K* __restrict__ keys, uint64_t n, int shift,
@@ -1592,6 +1614,76 @@ int rdst_hip_sort(void* host_data, uint64_t len, uint32_t elem_bytes, rdst_key_k
     // the host buffer is written only now, after the device reported success
     if ((e = hipMemcpyAsync(host_data, d_keys, bytes, hipMemcpyDeviceToHost, s)) != hipSuccess) { cleanup(); return fail(RDST_ERR_HIP, "D2H", e); }
     if ((e = hipStreamSynchronize(s)) != hipSuccess) { cleanup(); return fail(RDST_ERR_HIP, "sync", e); }
+    cleanup();
+    return RDST_OK;
+}
+
+int rdst_hip_sort_records(void* host_records, uint64_t len, uint32_t record_bytes, uint32_t key_offset, uint32_t key_bytes,
+                          rdst_key_kind kind, const rdst_hip_opts* opts) {
+    if (key_bytes != 4 && key_bytes != 8) return fail(RDST_ERR_UNSUPPORTED, "record sorts take a 4- or 8-byte key field");
+    if (kind == RDST_KEY_FLOAT || kind == RDST_KEY_SIGNED || kind == RDST_KEY_UNSIGNED) {} else return fail(RDST_ERR_ARG, "unknown key kind");
+    if (record_bytes == 0 || (uint64_t)key_offset + key_bytes > record_bytes) return fail(RDST_ERR_ARG, "key field outside the record");
+    if (key_offset % key_bytes || record_bytes % key_bytes) return fail(RDST_ERR_ALIGN, "key field not naturally aligned inside the record");
+    if (len > 0 && host_records == nullptr) return fail(RDST_ERR_ARG, "null record pointer");
+    if (len >= (1ull << 36)) return fail(RDST_ERR_ARG, "len too large");
+    if (len <= 1) return RDST_OK;
+    int prev_dev = -1;
+    if (opts && opts->device >= 0) {
+        HIP_TRY(hipGetDevice(&prev_dev));
+        HIP_TRY(hipSetDevice(opts->device));
+    }
+    const size_t bytes = (size_t)len * record_bytes;
+    const uint32_t idx_bytes = len < (1ull << 32) ? 4 : 8;
+    void *d_rec = nullptr, *d_out = nullptr, *d_keys = nullptr, *d_tk = nullptr, *d_idx = nullptr, *d_ti = nullptr;
+    hipStream_t s = nullptr;
+    auto cleanup = [&]() {
+        for (void* p : {d_rec, d_out, d_keys, d_tk, d_idx, d_ti})
+            if (p) (void)hipFree(p);
+        if (s) (void)hipStreamDestroy(s);
+        if (prev_dev >= 0) (void)hipSetDevice(prev_dev);
+    };
+    hipError_t e;
+#define RDST_REC_TRY(expr) if ((e = (expr)) != hipSuccess) { if (s) (void)hipStreamSynchronize(s); cleanup(); return fail(RDST_ERR_HIP, #expr, e); }
+    RDST_REC_TRY(hipStreamCreate(&s));
+    RDST_REC_TRY(hipMalloc(&d_rec, bytes));
+    RDST_REC_TRY(hipMalloc(&d_out, bytes));
+    RDST_REC_TRY(hipMalloc(&d_keys, (size_t)len * key_bytes));
+    RDST_REC_TRY(hipMalloc(&d_tk, (size_t)len * key_bytes));
+    RDST_REC_TRY(hipMalloc(&d_idx, (size_t)len * idx_bytes));
+    RDST_REC_TRY(hipMalloc(&d_ti, (size_t)len * idx_bytes));
+    RDST_REC_TRY(hipMemcpyAsync(d_rec, host_records, bytes, hipMemcpyHostToDevice, s));
+    uint64_t blocks = (len + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    const unsigned char* rec = static_cast<const unsigned char*>(d_rec);
+    if (key_bytes == 4) {
+        if (idx_bytes == 4) hipLaunchKernelGGL((extract_key_kernel<uint32_t, uint32_t>), dim3((uint32_t)blocks), dim3(256), 0, s, rec, len, record_bytes, key_offset, static_cast<uint32_t*>(d_keys), static_cast<uint32_t*>(d_idx));
+        else hipLaunchKernelGGL((extract_key_kernel<uint32_t, uint64_t>), dim3((uint32_t)blocks), dim3(256), 0, s, rec, len, record_bytes, key_offset, static_cast<uint32_t*>(d_keys), static_cast<uint64_t*>(d_idx));
+    } else {
+        if (idx_bytes == 4) hipLaunchKernelGGL((extract_key_kernel<uint64_t, uint32_t>), dim3((uint32_t)blocks), dim3(256), 0, s, rec, len, record_bytes, key_offset, static_cast<uint64_t*>(d_keys), static_cast<uint32_t*>(d_idx));
+        else hipLaunchKernelGGL((extract_key_kernel<uint64_t, uint64_t>), dim3((uint32_t)blocks), dim3(256), 0, s, rec, len, record_bytes, key_offset, static_cast<uint64_t*>(d_keys), static_cast<uint64_t*>(d_idx));
+    }
+    RDST_REC_TRY(hipGetLastError());
+    int rc = rdst_hip_sort_pairs_device(d_keys, d_idx, d_tk, d_ti, len, key_bytes, kind, key_bytes, idx_bytes, s);
+    if (rc == RDST_OK) rc = rdst_hip_device_status(s);
+    if (rc != RDST_OK) { (void)hipStreamSynchronize(s); cleanup(); return rc; }
+    // rows in the order of the sorted indices, in the widest units the row size allows
+    const uint32_t unit = record_bytes % 16 == 0 ? 16 : (record_bytes % 8 == 0 ? 8 : 4);
+    const uint64_t total_units = len * (record_bytes / unit);
+    uint64_t gblocks = (total_units + 255) / 256;
+    if (gblocks > 256 * 32) gblocks = 256 * 32;
+    struct alignas(16) U16 { uint64_t a, b; };
+#define RDST_GATHER(UT, IT) hipLaunchKernelGGL((gather_records_kernel<UT, IT>), dim3((uint32_t)gblocks), dim3(256), 0, s, static_cast<const UT*>(d_rec), static_cast<UT*>(d_out), static_cast<const IT*>(d_idx), len, record_bytes / unit)
+    if (idx_bytes == 4) {
+        if (unit == 16) RDST_GATHER(U16, uint32_t); else if (unit == 8) RDST_GATHER(uint64_t, uint32_t); else RDST_GATHER(uint32_t, uint32_t);
+    } else {
+        if (unit == 16) RDST_GATHER(U16, uint64_t); else if (unit == 8) RDST_GATHER(uint64_t, uint64_t); else RDST_GATHER(uint32_t, uint64_t);
+    }
+#undef RDST_GATHER
+    RDST_REC_TRY(hipGetLastError());
+    // the host buffer is written only now, after the device reported success
+    RDST_REC_TRY(hipMemcpyAsync(host_records, d_out, bytes, hipMemcpyDeviceToHost, s));
+    RDST_REC_TRY(hipStreamSynchronize(s));
+#undef RDST_REC_TRY
     cleanup();
     return RDST_OK;
 }

@@ -168,6 +168,23 @@ def sort_host_array(arr, device=-1, key=None):
     _lib.check(lib.rdst_hip_sort(ctypes.c_void_p(arr.ctypes.data), arr.nbytes // nbytes, nbytes, kind, levels, ctypes.byref(opts)))
 
 
+def sort_host_records(arr, field, device=-1):
+    """``rdst_hip_sort_records`` on a numpy structured array, in place: the rows are ordered by ``field``
+    (a 4- or 8-byte integer or float field); rows with equal keys keep their order."""
+    if not isinstance(arr, np.ndarray) or arr.dtype.fields is None or arr.ndim != 1:
+        raise ValueError("need a 1-D numpy structured array")
+    if not arr.flags.c_contiguous or not arr.flags.writeable:
+        raise ValueError("need a writeable C-contiguous array (rdst sorts a mutable slice)")
+    ftype, offset = arr.dtype.fields[field][:2]
+    kind, nbytes, _levels = key_info(ftype.name)
+    if arr.shape[0] <= 1:
+        return
+    lib = _lib.load()
+    opts = _lib.HipOptsC(int(device), 0, 0)
+    _lib.check(lib.rdst_hip_sort_records(ctypes.c_void_p(arr.ctypes.data), arr.shape[0], arr.dtype.itemsize, int(offset), nbytes, kind,
+                                         ctypes.byref(opts)))
+
+
 class RadixSortBuilder:
     """src/radix_sort_builder.rs:8-158.  ``with_parallel`` and the CPU tuners are accepted for
     source compatibility; they select among the reference's CPU algorithms, which this package

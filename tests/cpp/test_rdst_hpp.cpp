@@ -38,8 +38,34 @@ static int check_float(std::size_t n, unsigned seed) {
     return same_bits<T, U>(v, expect) ? 0 : 1;
 }
 
+// benches/struct_sort.rs:11-27: a large struct sorted by one f32 field
+struct LargeStruct {
+    std::uint64_t a;
+    float sort_key;
+    std::uint32_t id;
+    double payload[5];
+};
+
+static int check_struct(std::size_t n, unsigned seed) {
+    std::mt19937_64 rng(seed);
+    std::vector<LargeStruct> v(n);
+    for (std::size_t i = 0; i < n; ++i) {
+        const std::uint32_t bits = static_cast<std::uint32_t>(rng()) & 0xC07FFFFFu;  // few exponents: many equal keys
+        std::memcpy(&v[i].sort_key, &bits, 4);
+        v[i].a = rng();
+        v[i].id = static_cast<std::uint32_t>(i);
+        for (double& p : v[i].payload) p = static_cast<double>(rng() % 1000);
+    }
+    std::vector<LargeStruct> expect = v;
+    auto key = [](float f) { std::uint32_t u; std::memcpy(&u, &f, 4); return (u & 0x80000000u) ? ~u : (u ^ 0x80000000u); };
+    std::stable_sort(expect.begin(), expect.end(), [&](const LargeStruct& x, const LargeStruct& y) { return key(x.sort_key) < key(y.sort_key); });
+    rdst::radix_sort_unstable_by_field(v, &LargeStruct::sort_key);
+    return std::memcmp(v.data(), expect.data(), n * sizeof(LargeStruct)) == 0 ? 0 : 1;
+}
+
 int main() {
     int bad = 0;
+    for (std::size_t n : {0ul, 1ul, 2ul, 1000ul, 250001ul}) bad += check_struct(n, 11);
     std::vector<std::uint32_t> doc = {3, 1, 2};  // src/radix_sort.rs:11-14
     rdst::radix_sort_unstable(doc);
     bad += !(doc == std::vector<std::uint32_t>{1, 2, 3});

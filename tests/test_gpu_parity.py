@@ -131,6 +131,24 @@ def test_records_sorted_by_a_key_field(gpu):
     assert np.array_equal(out.view(np.uint32), rec[order].view(np.uint32))
 
 
+@pytest.mark.parametrize("ktype", ["<f4", "<i8", "<u4", "<f8"])
+def test_host_records_entry_point(gpu, ktype):
+    """rdst_hip_sort_records: a host slice of structs ordered by one built-in field, rows moved whole."""
+    rng = np.random.default_rng(31)
+    for rec_dt in (np.dtype([("id", "<u4"), ("key", ktype), ("pad", "<u4")], align=True),
+                   np.dtype([("w", "<f8", (3,)), ("key", ktype), ("tag", "<u8")], align=True)):
+        for n in (0, 1, 2, 1000, 123_457):
+            a = np.zeros(n, dtype=rec_dt)
+            raw = rng.integers(0, 256, size=(n, rec_dt.itemsize), dtype=np.uint8)
+            a.view(np.uint8).reshape(n, rec_dt.itemsize)[:] = raw
+            if n > 10:
+                a["key"][::3] = a["key"][0]  # repeated keys
+            order = np.argsort(mapped_key(a["key"].copy()), kind="stable")
+            exp = a.view(np.uint8).reshape(n, rec_dt.itemsize)[order].copy()  # whole rows, padding bytes included
+            gpu.sort_host_records(a, "key")
+            assert np.array_equal(a.view(np.uint8).reshape(n, rec_dt.itemsize), exp), (ktype, rec_dt.itemsize, n)
+
+
 @pytest.mark.parametrize("dtype", SMALL_DTYPES)
 def test_narrow_key_types(gpu, oracle, dtype):
     """u8 / u16 / i8 / i16 (src/radix_key_impl.rs:3-19, :87-103): one- and two-level keys."""
