@@ -80,6 +80,7 @@ struct LowMemoryTuner : Tuner {  // src/tuners/low_memory_tuner.rs:13-43
 struct SingleThreadedTuner : Tuner {  // src/tuners/single_threaded_tuner.rs:13-43
     Algorithm pick_algorithm(const TuningParams& p, const std::uint64_t (&c)[256]) const override { return detail::table(RDST_TUNER_SINGLE_THREADED, p, c, 0); }
 };
+constexpr std::uint64_t kGpuMinLenHostSlice = RDST_GPU_MIN_LEN_HOST_SLICE;  // where a host slice is better off on the device
 struct GpuTuner : Tuner {  // StandardTuner, except whole top-level slices of >= gpu_min_len elements go to the device
     std::uint64_t gpu_min_len = 0;
     explicit GpuTuner(std::uint64_t min_len = 0) : gpu_min_len(min_len) {}

@@ -38,9 +38,14 @@ class HipEngine:
         return np.asarray(counts, dtype=np.int64)
 
     def scatter_top_level(self, keys):
+        return self.scatter_top_level_with_counts(keys)[0]
+
+    def scatter_top_level_with_counts(self, keys):
+        """One call: the scatter hook counts the level it moves (its K1), so the 256 top-level counts
+        come with the grouped shard and no separate counting sweep is needed."""
         levels = _rs.key_info(keys.dtype)[2]
-        dst, _ = _rs.scatter_level(keys, levels - 1)
-        return dst
+        dst, counts = _rs.scatter_level(keys, levels - 1)
+        return dst, np.asarray(counts, dtype=np.int64)
 
     def sort(self, keys, tmp=None):
         _rs.sort_device_tensor(keys, tmp)
@@ -86,8 +91,15 @@ def sharded_sort(local_keys, group=None, engine=None, return_info: bool = False)
     # sharing one GPU) device tensors are staged through the host for the two collectives.
     via_host = local_keys.is_cuda and dist.get_backend(group) == "gloo"
     cdev = torch.device("cpu") if via_host else dev
-    # 1-2. local histogram, all-gather (2 KiB per rank)
-    mine = torch.from_numpy(engine.top_level_counts(local_keys)).to(cdev)
+    # 1 + 4. group my shard by top digit — one stable pass; owners are contiguous digit ranges, so this
+    # is also the grouping by owner — and take the 256 counts the pass had to make anyway
+    if hasattr(engine, "scatter_top_level_with_counts"):
+        grouped, counts = engine.scatter_top_level_with_counts(local_keys)
+    else:
+        counts = engine.top_level_counts(local_keys)
+        grouped = engine.scatter_top_level(local_keys)
+    # 2. all-gather (2 KiB per rank)
+    mine = torch.from_numpy(np.ascontiguousarray(counts, dtype=np.int64)).to(cdev)
     gathered = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(gathered, mine, group=group)
     table = torch.stack(gathered).cpu().numpy()  # [rank][digit]
@@ -96,8 +108,6 @@ def sharded_sort(local_keys, group=None, engine=None, return_info: bool = False)
     # send split: my keys per destination; receive split: every source's keys for my range
     send = [int(table[rank][owner == r].sum()) for r in range(world)]
     recv = [int(table[src][owner == rank].sum()) for src in range(world)]
-    # 4. group my shard by owner: one stable pass on the top digit
-    grouped = engine.scatter_top_level(local_keys)
     # 5. exchange
     inbox = engine.empty(sum(recv), local_keys)
     as_int = {1: torch.int8, 2: torch.int16, 4: torch.int32, 8: torch.int64}[local_keys.element_size()]
