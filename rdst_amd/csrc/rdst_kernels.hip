@@ -815,36 +815,48 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8,
     //    STAGES == 1: the key goes straight to its slot of the LDS staging buffer (step 6).
     //    STAGES  > 1: the tile is larger than the staging buffer; slots are kept (16-bit pairs).
     uint32_t slots[STAGES > 1 ? KPT / 2 : 1];
-#pragma unroll
-    for (int i = 0; i < KPT; ++i) {
-        uint32_t* slot = &wh[digit_of(mk[i], shift)];
-        const uint32_t b = *slot;
-        uint32_t below;
-        if ((uniform_rounds >> i) & 1u) {  // wave-uniform branch
-            below = (uint32_t)lane;
-            __builtin_amdgcn_wave_barrier();
-            if (lane == 0) *slot = b + 64u;
-        } else if (careful) {              // heavy digits: the group's first lane advances the slot
-            uint32_t total;
-            below = peers_below_total(digit_word<K>(mk[i], shift), bit0, total);
-            __builtin_amdgcn_wave_barrier();
-            if (below == 0) *slot = b + total;
-        } else {
-            below = RDST_ABL(3) ? 0u : peers_below(digit_word<K>(mk[i], shift), bit0);
-            __builtin_amdgcn_wave_barrier();
-            atomicAdd(slot, 1u);
-        }
+    auto place = [&](int i, uint32_t sl) {  // key i of this lane goes to slot sl of the tile
         if constexpr (STAGES == 1) {
-            s_keys[b + below] = mk[i];
-            if constexpr (HAS_V) s_vals[b + below] = mv[i];
+            s_keys[sl] = mk[i];
+            if constexpr (HAS_V) s_vals[sl] = mv[i];
         } else {
-            uint32_t sl = b + below;
             // pin the slot here: its inputs are eight ballots (SGPR pairs); left alone the
             // compiler sinks the arithmetic to the first use, after the look-back, and keeps
             // every round's ballots alive (KPT * 8 SGPR pairs -> spills)
             asm volatile("" : "+v"(sl));
             if (i & 1) slots[i >> 1] |= sl << 16;
             else slots[i >> 1] = sl;
+        }
+    };
+    // two separate loops: sharing one loop body lets the compiler hoist half of the bit tests above
+    // the (wave-uniform) choice and pay for them twice on the plain path
+    if (!careful) {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            uint32_t* slot = &wh[digit_of(mk[i], shift)];
+            const uint32_t b = *slot;
+            const uint32_t below = RDST_ABL(3) ? 0u : peers_below(digit_word<K>(mk[i], shift), bit0);
+            __builtin_amdgcn_wave_barrier();
+            atomicAdd(slot, 1u);
+            place(i, b + below);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            uint32_t* slot = &wh[digit_of(mk[i], shift)];
+            const uint32_t b = *slot;
+            uint32_t below;
+            if ((uniform_rounds >> i) & 1u) {  // one digit in all 64 lanes
+                below = (uint32_t)lane;
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) *slot = b + 64u;
+            } else {                           // heavy digits: the group's first lane advances the slot
+                uint32_t total;
+                below = peers_below_total(digit_word<K>(mk[i], shift), bit0, total);
+                __builtin_amdgcn_wave_barrier();
+                if (below == 0) *slot = b + total;
+            }
+            place(i, b + below);
         }
     }
 
