@@ -22,6 +22,7 @@
 #include <stdexcept>
 #include <string>
 #include <type_traits>
+#include <array>
 #include <vector>
 
 #include "rdst_hip.h"
@@ -42,6 +43,11 @@ struct RadixKey<T, std::enable_if_t<std::is_integral_v<T> && !std::is_same_v<T, 
 };
 template <> struct RadixKey<float> { static constexpr std::size_t LEVELS = 4; static constexpr rdst_key_kind kind = RDST_KEY_FLOAT; };
 template <> struct RadixKey<double> { static constexpr std::size_t LEVELS = 8; static constexpr rdst_key_kind kind = RDST_KEY_FLOAT; };
+template <std::size_t N>
+struct RadixKey<std::array<std::uint8_t, N>, std::enable_if_t<(N >= 1 && N <= 16)>> {  // [u8; N], src/radix_key_impl.rs:78-85: lexicographic
+    static constexpr std::size_t LEVELS = N;
+    static constexpr rdst_key_kind kind = RDST_KEY_BYTES_BE;
+};
 
 namespace tuner {
 
@@ -127,6 +133,9 @@ class RadixSortBuilder {  // src/radix_sort_builder.rs:8-158
 
    private:
     static std::uint8_t top_digit(const T& v, int level) {  // RadixKey::get_level (src/radix_key_impl.rs)
+        if constexpr (RadixKey<T>::kind == RDST_KEY_BYTES_BE) {
+            return reinterpret_cast<const std::uint8_t*>(&v)[RadixKey<T>::LEVELS - 1 - static_cast<std::size_t>(level)];
+        } else {
         using U = std::conditional_t<sizeof(T) == 1, std::uint8_t, std::conditional_t<sizeof(T) == 2, std::uint16_t,
                   std::conditional_t<sizeof(T) == 4, std::uint32_t, std::uint64_t>>>;
         U u;
@@ -135,6 +144,7 @@ class RadixSortBuilder {  // src/radix_sort_builder.rs:8-158
         if (RadixKey<T>::kind == RDST_KEY_SIGNED) u = U(u ^ msb);
         else if (RadixKey<T>::kind == RDST_KEY_FLOAT) u = U(u ^ ((u & msb) ? U(~U(0)) : msb));
         return static_cast<std::uint8_t>(u >> (level * 8));
+        }
     }
 };
 

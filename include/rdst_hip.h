@@ -36,13 +36,15 @@ extern "C" {
 typedef enum {
     RDST_KEY_UNSIGNED = 0, /* u8..u64: (self >> level*8) as u8          radix_key_impl.rs:3-76   */
     RDST_KEY_SIGNED   = 1, /* i8..i64: ((self ^ MIN) >> level*8) as u8  radix_key_impl.rs:87-160 */
-    RDST_KEY_FLOAT    = 2  /* f32/f64: sign-magnitude flip, then ^ MIN  radix_key_impl.rs:162-185 */
+    RDST_KEY_FLOAT    = 2, /* f32/f64: sign-magnitude flip, then ^ MIN  radix_key_impl.rs:162-185 */
+    RDST_KEY_BYTES_BE = 3  /* [u8; N]: self[N - 1 - level], i.e. lexicographic  radix_key_impl.rs:78-85;
+                              N = elem_bytes = levels in 1..16, host entry point only */
 } rdst_key_kind;
 
 typedef enum {
     RDST_OK              = 0,
     RDST_ERR_ARG         = -1, /* bad pointer / size / kind / levels (LEVELS == 0 panics in rdst: radix_sort_builder.rs:22) */
-    RDST_ERR_UNSUPPORTED = -2, /* element width / kind not built for the device path (built: 1-, 2-, 4-, 8-, 16-byte integers, f32, f64) */
+    RDST_ERR_UNSUPPORTED = -2, /* element width / kind not built for the device path (built: 1-, 2-, 4-, 8-, 16-byte integers, f32, f64, [u8; 1..16] through rdst_hip_sort) */
     RDST_ERR_HIP         = -3, /* a HIP runtime call failed; see rdst_hip_last_error() */
     RDST_ERR_NO_DEVICE   = -4, /* no usable gfx950 device */
     RDST_ERR_DEVICE      = -5, /* a kernel reported failure through the workspace error word (bounded spin expired) */

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librdst_hip.so")
 
-RDST_KEY_UNSIGNED, RDST_KEY_SIGNED, RDST_KEY_FLOAT = 0, 1, 2
+RDST_KEY_UNSIGNED, RDST_KEY_SIGNED, RDST_KEY_FLOAT, RDST_KEY_BYTES_BE = 0, 1, 2, 3
 RDST_OK = 0
 
 # every symbol include/rdst_hip.h declares; tests check that the library exports all of them

@@ -985,6 +985,29 @@ __global__ __launch_bounds__(256) void copyback_kernel(K* __restrict__ keys, con
     }
 }
 
+// [u8; N] keys (src/radix_key_impl.rs:78-85: level l reads byte N-1-l, i.e. lexicographic order): the
+// N bytes become the low N bytes of an unsigned W-byte integer, first byte most significant; the
+// integer sort then skips the W-N constant top levels by itself.  And back.
+template <typename K>
+__global__ __launch_bounds__(256) void bytes_expand_kernel(const unsigned char* __restrict__ raw, K* __restrict__ out, uint64_t n, uint32_t nb) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const unsigned char* p = raw + i * nb;
+        K v = 0;
+        for (uint32_t j = 0; j < nb; ++j) v = (K)(v << 8) | (K)p[j];
+        out[i] = v;
+    }
+}
+template <typename K>
+__global__ __launch_bounds__(256) void bytes_compact_kernel(const K* __restrict__ in, unsigned char* __restrict__ raw, uint64_t n, uint32_t nb) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        unsigned char* p = raw + i * nb;
+        K v = in[i];
+        for (uint32_t j = nb; j-- > 0;) { p[j] = (unsigned char)v; v >>= 8; }
+    }
+}
+
 // Records with a built-in key field: (key, row index) pairs out of the rows, and
 // the rows back in the order of the sorted indices.  UNIT = widest word the row size allows.
 template <typename K, typename I>
@@ -1447,7 +1470,8 @@ int check_common(const void* p, uint64_t len, uint32_t elem_bytes, rdst_key_kind
     if (kind == RDST_KEY_FLOAT && elem_bytes != 4 && elem_bytes != 8) return fail(RDST_ERR_UNSUPPORTED, "float keys are f32 / f64");
     if (levels == 0) return fail(RDST_ERR_ARG, "RadixKey must have at least 1 level");
     if (levels != elem_bytes) return fail(RDST_ERR_ARG, "levels must equal the element width for built-in key types");
-    if ((int)kind < 0 || (int)kind > 2) return fail(RDST_ERR_ARG, "unknown key kind");
+    if (kind == RDST_KEY_BYTES_BE) return fail(RDST_ERR_UNSUPPORTED, "[u8; N] keys go through the host entry point rdst_hip_sort");
+    if ((int)kind < 0 || (int)kind > 3) return fail(RDST_ERR_ARG, "unknown key kind");
     if (len > 0 && p == nullptr) return fail(RDST_ERR_ARG, "null key pointer");
     if (reinterpret_cast<uintptr_t>(p) % elem_bytes) return fail(RDST_ERR_ALIGN, "key pointer not aligned to the element size");
     if (len >= (1ull << 36)) return fail(RDST_ERR_ARG, "len too large");
@@ -1604,8 +1628,64 @@ int rdst_hip_device_status(void* stream) {
     return read_device_error(*D, s);
 }
 
+namespace {
+// [u8; N] host slice: H2D of the raw bytes, expand to W-byte integers, sort those, compact, D2H
+int sort_byte_keys_host(void* host_data, uint64_t len, uint32_t nb, const rdst_hip_opts* opts) {
+    int prev_dev = -1;
+    if (opts && opts->device >= 0) {
+        HIP_TRY(hipGetDevice(&prev_dev));
+        HIP_TRY(hipSetDevice(opts->device));
+    }
+    const uint32_t w = nb <= 4 ? 4 : (nb <= 8 ? 8 : 16);
+    void *d_raw = nullptr, *d_keys = nullptr, *d_tmp = nullptr;
+    hipStream_t s = nullptr;
+    auto cleanup = [&]() {
+        for (void* p : {d_raw, d_keys, d_tmp})
+            if (p) (void)hipFree(p);
+        if (s) (void)hipStreamDestroy(s);
+        if (prev_dev >= 0) (void)hipSetDevice(prev_dev);
+    };
+    hipError_t e;
+#define RDST_B_TRY(expr) if ((e = (expr)) != hipSuccess) { if (s) (void)hipStreamSynchronize(s); cleanup(); return fail(RDST_ERR_HIP, #expr, e); }
+    RDST_B_TRY(hipStreamCreate(&s));
+    RDST_B_TRY(hipMalloc(&d_raw, (size_t)len * nb));
+    RDST_B_TRY(hipMalloc(&d_keys, (size_t)len * w));
+    RDST_B_TRY(hipMalloc(&d_tmp, (size_t)len * w));
+    RDST_B_TRY(hipMemcpyAsync(d_raw, host_data, (size_t)len * nb, hipMemcpyHostToDevice, s));
+    uint64_t blocks = (len + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    const unsigned char* raw = static_cast<const unsigned char*>(d_raw);
+    if (w == 4) hipLaunchKernelGGL((bytes_expand_kernel<uint32_t>), dim3((uint32_t)blocks), dim3(256), 0, s, raw, static_cast<uint32_t*>(d_keys), len, nb);
+    else if (w == 8) hipLaunchKernelGGL((bytes_expand_kernel<uint64_t>), dim3((uint32_t)blocks), dim3(256), 0, s, raw, static_cast<uint64_t*>(d_keys), len, nb);
+    else hipLaunchKernelGGL((bytes_expand_kernel<u128>), dim3((uint32_t)blocks), dim3(256), 0, s, raw, static_cast<u128*>(d_keys), len, nb);
+    RDST_B_TRY(hipGetLastError());
+    int rc = rdst_hip_sort_device(d_keys, d_tmp, len, w, RDST_KEY_UNSIGNED, w, s);
+    if (rc == RDST_OK) rc = rdst_hip_device_status(s);
+    if (rc != RDST_OK) { (void)hipStreamSynchronize(s); cleanup(); return rc; }
+    unsigned char* rawo = static_cast<unsigned char*>(d_raw);
+    if (w == 4) hipLaunchKernelGGL((bytes_compact_kernel<uint32_t>), dim3((uint32_t)blocks), dim3(256), 0, s, static_cast<const uint32_t*>(d_keys), rawo, len, nb);
+    else if (w == 8) hipLaunchKernelGGL((bytes_compact_kernel<uint64_t>), dim3((uint32_t)blocks), dim3(256), 0, s, static_cast<const uint64_t*>(d_keys), rawo, len, nb);
+    else hipLaunchKernelGGL((bytes_compact_kernel<u128>), dim3((uint32_t)blocks), dim3(256), 0, s, static_cast<const u128*>(d_keys), rawo, len, nb);
+    RDST_B_TRY(hipGetLastError());
+    // the host buffer is written only now, after the device reported success
+    RDST_B_TRY(hipMemcpyAsync(host_data, d_raw, (size_t)len * nb, hipMemcpyDeviceToHost, s));
+    RDST_B_TRY(hipStreamSynchronize(s));
+#undef RDST_B_TRY
+    cleanup();
+    return RDST_OK;
+}
+}  // namespace
+
 int rdst_hip_sort(void* host_data, uint64_t len, uint32_t elem_bytes, rdst_key_kind kind, uint32_t levels,
                   const rdst_hip_opts* opts) {
+    if (kind == RDST_KEY_BYTES_BE) {  // [u8; N], src/radix_key_impl.rs:78-85
+        if (elem_bytes == 0 || elem_bytes > 16) return fail(RDST_ERR_UNSUPPORTED, "[u8; N] keys are built for N in 1..16");
+        if (levels != elem_bytes) return fail(RDST_ERR_ARG, "levels must equal N for [u8; N]");
+        if (len > 0 && host_data == nullptr) return fail(RDST_ERR_ARG, "null key pointer");
+        if (len >= (1ull << 36)) return fail(RDST_ERR_ARG, "len too large");
+        if (len <= 1) return RDST_OK;
+        return sort_byte_keys_host(host_data, len, elem_bytes, opts);
+    }
     int rc = check_common(host_data, len, elem_bytes, kind, levels);
     if (rc) return rc;
     if (len <= 1) return RDST_OK;

@@ -153,9 +153,21 @@ def device_status(device=None):
 
 
 def sort_host_array(arr, device=-1, key=None):
-    """``rdst_hip_sort`` on a host numpy array (H2D, device sort, D2H), in place."""
+    """``rdst_hip_sort`` on a host numpy array (H2D, device sort, D2H), in place.  ``key="bytes"``: a uint8
+    array of shape (n, N), N in 1..16, each row one ``[u8; N]`` key (src/radix_key_impl.rs:78-85: rows
+    end up in lexicographic order)."""
     if not isinstance(arr, np.ndarray) or not arr.flags.c_contiguous or not arr.flags.writeable:
         raise ValueError("need a writeable C-contiguous 1-D numpy array (rdst sorts a mutable slice)")
+    if key == "bytes":
+        if arr.ndim != 2 or arr.dtype != np.uint8 or not 1 <= arr.shape[1] <= 16:
+            raise ValueError("[u8; N] keys: a uint8 array of shape (n, N) with N in 1..16")
+        if arr.shape[0] <= 1:
+            return
+        n_bytes = int(arr.shape[1])
+        opts = _lib.HipOptsC(int(device), 0, 0)
+        _lib.check(_lib.load().rdst_hip_sort(ctypes.c_void_p(arr.ctypes.data), arr.shape[0], n_bytes, _lib.RDST_KEY_BYTES_BE, n_bytes,
+                                             ctypes.byref(opts)))
+        return
     if _wide(key):
         _check_wide_shape(arr.shape, arr.dtype.itemsize)
     elif arr.ndim != 1:
@@ -217,6 +229,8 @@ class RadixSortBuilder:
 
     def _len_and_levels(self):
         d = self._data
+        if self._key == "bytes":  # [u8; N] rows of a (n, N) uint8 array
+            return int(d.shape[0]), int(d.shape[1])
         if self._key:
             _, nbytes, levels = key_info(self._key)
             total = d.numel() * d.element_size() if _is_torch_tensor(d) else d.nbytes
@@ -241,6 +255,8 @@ class RadixSortBuilder:
                     f"tuner picked {Algorithm(algo).name}: the CPU algorithms stay in the reference crate; "
                     "this package implements the device route (Algorithm.GpuLsd) only")
         if _is_torch_tensor(self._data):
+            if self._key == "bytes":
+                raise NotImplementedError("[u8; N] keys go through the host entry point: pass a numpy array")
             sort_device_tensor(self._data, key=self._key)
         else:
             sort_host_array(self._data, key=self._key)
@@ -307,8 +323,12 @@ def scatter_level(src, level, dst=None):
 
 def radix_sort_builder(data, key=None) -> RadixSortBuilder:
     """``RadixSort::radix_sort_builder`` (src/radix_sort.rs:29-31 / :42-44).  ``key``: "u128" / "i128"
-    for (n, 2) limb containers; otherwise the key type is the container's dtype."""
-    n_levels = key_info(key if key else (data.dtype if _is_torch_tensor(data) else data.dtype.name))[2]
+    for (n, 2) limb containers, "bytes" for a (n, N) uint8 array of ``[u8; N]`` keys; otherwise the key
+    type is the container's dtype."""
+    if key == "bytes":
+        n_levels = int(data.shape[1]) if getattr(data, "ndim", 0) == 2 else 0
+    else:
+        n_levels = key_info(key if key else (data.dtype if _is_torch_tensor(data) else data.dtype.name))[2]
     assert n_levels != 0, "RadixKey must have at least 1 level"  # radix_sort_builder.rs:22
     return RadixSortBuilder(data, key)
 

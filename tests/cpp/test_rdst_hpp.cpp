@@ -2,6 +2,7 @@
 // (src/radix_sort.rs:146-340: random input, compare with the standard library's sort).
 // Built and run by tests/test_cpp_mirror.py.  Exit code 0 = all checks passed.
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -63,8 +64,24 @@ static int check_struct(std::size_t n, unsigned seed) {
     return std::memcmp(v.data(), expect.data(), n * sizeof(LargeStruct)) == 0 ? 0 : 1;
 }
 
+template <std::size_t N>
+static int check_bytes(std::size_t n, unsigned seed) {  // [u8; N] sorts lexicographically (src/radix_sort.rs:221-229)
+    std::mt19937_64 rng(seed);
+    std::vector<std::array<std::uint8_t, N>> v(n);
+    for (auto& a : v) for (auto& b : a) b = static_cast<std::uint8_t>(rng() % 5 ? rng() : 0);
+    auto expect = v;
+    std::sort(expect.begin(), expect.end());
+    rdst::radix_sort_unstable(v);
+    return v == expect ? 0 : 1;
+}
+
 int main() {
     int bad = 0;
+    std::vector<std::array<std::uint8_t, 3>> arr = {{1, 2, 3}, {3, 2, 1}, {3, 3, 3}, {0, 255, 7}};  // src/radix_sort.rs:221-229
+    rdst::radix_sort_unstable(arr);
+    bad += !(arr == std::vector<std::array<std::uint8_t, 3>>{{0, 255, 7}, {1, 2, 3}, {3, 2, 1}, {3, 3, 3}});
+    for (std::size_t n : {0ul, 1ul, 2ul, 1000ul, 300007ul})
+        bad += check_bytes<1>(n, 21) + check_bytes<3>(n, 22) + check_bytes<4>(n, 23) + check_bytes<7>(n, 24) + check_bytes<8>(n, 25) + check_bytes<11>(n, 26) + check_bytes<16>(n, 27);
     for (std::size_t n : {0ul, 1ul, 2ul, 1000ul, 250001ul}) bad += check_struct(n, 11);
     std::vector<std::uint32_t> doc = {3, 1, 2};  // src/radix_sort.rs:11-14
     rdst::radix_sort_unstable(doc);

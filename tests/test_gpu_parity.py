@@ -131,6 +131,30 @@ def test_records_sorted_by_a_key_field(gpu):
     assert np.array_equal(out.view(np.uint32), rec[order].view(np.uint32))
 
 
+def test_byte_array_keys(gpu, oracle):
+    """[u8; N] (src/radix_key_impl.rs:78-85): level l reads byte N-1-l, rows end up in lexicographic order —
+    the reference's own known answer (src/radix_sort.rs:221-229), the oracle's b3 / b4 types, numpy lexsort."""
+    ka = json.load(open(os.path.join(HERE, "golden", "reference_known_answers.json")))
+    for case in ka["sorts"]:
+        if case["type"] in ("b3", "b4"):
+            a = np.array(case["input"], dtype=np.uint8)
+            gpu.radix_sort_unstable(a, key="bytes")
+            assert a.tolist() == case["expected"], case["source"]
+    rng = np.random.default_rng(808)
+    for nb in range(1, 17):
+        for n in (0, 1, 2, 257, 100_003):
+            a = rng.integers(0, 256, size=(n, nb), dtype=np.uint8)
+            a[rng.random((n, nb)) < 0.3] = 0  # ties on leading bytes
+            exp = a[np.lexsort(a.T[::-1])] if n else a.copy()
+            if nb in (3, 4) and n:
+                o = a.copy()
+                oracle.sort(o, threads=2, kind=f"b{nb}")
+                assert np.array_equal(o, exp)
+            got = a.copy()
+            gpu.radix_sort_unstable(got, key="bytes")
+            assert np.array_equal(got, exp), (nb, n)
+
+
 @pytest.mark.parametrize("ktype", ["<f4", "<i8", "<u4", "<f8"])
 def test_host_records_entry_point(gpu, ktype):
     """rdst_hip_sort_records: a host slice of structs ordered by one built-in field, rows moved whole."""
