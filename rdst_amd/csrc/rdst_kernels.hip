@@ -53,6 +53,15 @@ template <typename S> struct StatusWord {
 // bounded spins: s_sleep(2) is ~128 clocks; 1<<22 polls is seconds, never reached in a healthy run
 constexpr uint32_t SPIN_LIMIT = 1u << 22;
 
+#ifndef RDST_PRIO_LOAD
+#define RDST_PRIO_LOAD 2
+#endif
+#ifndef RDST_PRIO_LB
+#define RDST_PRIO_LB 0
+#endif
+#ifndef RDST_PRIO_SCATTER
+#define RDST_PRIO_SCATTER 2
+#endif
 #ifndef RDST_LB_WINDOW
 #define RDST_LB_WINDOW 8  // predecessor status words fetched per look-back round trip
 #endif
@@ -651,6 +660,10 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8,
     // predecessors have always started; when that chain is handed out it tries the next ones
     // (segments of a skewed pass differ in length).  The grid has at least one block per tile.
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // Wave priority: the phases that issue memory traffic (the tile's loads, the look-back, the
+    // scatter) go ahead of other waves' arithmetic (counting, ranking), so the memory pipeline is fed
+    // while the vector ALU works through the ranking of the CU's other block.  A/B: pass 1.84 -> 1.75 ms.
+    __builtin_amdgcn_s_setprio(RDST_PRIO_LOAD);
     if (tid == 0) {
         // The chain's table entries and the mask of chains already handed out are requested before
         // the ticket, so that only arithmetic follows the atomic's round trip.  A block that finds
@@ -739,6 +752,7 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8,
         }
     }
 
+    __builtin_amdgcn_s_setprio(0);
     // 2. per-wave 256-bin histogram in LDS ("early counts")
     uint32_t* wh = wave_hist + wave * RADIX;
 #pragma unroll
@@ -869,6 +883,7 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8,
     }
 
     // 7. decoupled look-back over the earlier tiles (thread d walks digit d)
+    __builtin_amdgcn_s_setprio(RDST_PRIO_LB);
     if (tid < RADIX) {
         uint64_t excl = 0;
         bool fail = false;
@@ -894,6 +909,7 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8,
     }
     __syncthreads();
     if (s_misc[1]) return;  // never store with an unknown prefix
+    __builtin_amdgcn_s_setprio(RDST_PRIO_SCATTER);
 
     // 6 + 8. per stage: (STAGES > 1) keys whose slot falls into the stage go to the LDS buffer;
     //    then consecutive threads take consecutive slots of a digit's run and store them.  LDS
