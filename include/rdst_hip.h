@@ -183,6 +183,12 @@ int rdst_hip_set_tuning(int pass_config, int hist_blocks_per_cu);
  * Results are identical either way.  Not part of the reference surface. */
 int rdst_hip_set_chain_split(int enabled);
 
+/* Experiment knob: enabled == 0 ranks every round of a scatter pass with wave ballots; the default
+ * takes the slots a returning LDS add hands out and falls back to the ballots for any round whose
+ * result fails the in-kernel order test (rdst_kernels.hip, step 5).  enabled == 2: self-test mode, every
+ * round is treated as failed and redone (exercises the fallback).  Results are identical in all modes. */
+int rdst_hip_set_fast_rank(int enabled);
+
 /* Per-kernel device timing for benchmarks.  While enabled, every pipeline (sort / hook call)
  * records HIP events on its own stream between its launches and appends one "run" to a
  * per-device list; enabling again clears the list.  rdst_hip_profile_run blocks until run

@@ -65,6 +65,8 @@ constexpr uint32_t SPIN_LIMIT = 1u << 22;
 #ifndef RDST_LB_WINDOW
 #define RDST_LB_WINDOW 8  // predecessor status words fetched per look-back round trip
 #endif
+constexpr uint32_t RDST_FAST_RANK = 1u << 16;  // bit of the pass kernel's flag word (its low bits: ablation switches of tools/ builds)
+constexpr uint32_t RDST_FAST_RANK_SELFTEST = 1u << 17;  // treat every round of the fast ranking as failed: exercises its fallback
 constexpr uint32_t ERR_LOOKBACK_TIMEOUT = 1;
 constexpr uint32_t ERR_SCATTER_RANGE = 2;  // a computed destination fell outside [0, n): never stored
 
@@ -619,7 +621,6 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8,
 #define RDST_ABL(bit) (((ablate) >> (bit)) & 1u)
 #else
 #define RDST_ABL(bit) false
-    (void)ablate;
 #endif
     constexpr int BLOCK = NWAVES * 64;
     constexpr int TILE = BLOCK * KPT;
@@ -850,8 +851,40 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8,
             else slots[i >> 1] = sl;
         }
     };
-    // two separate loops: sharing one loop body lets the compiler hoist half of the bit tests above
-    // the (wave-uniform) choice and pay for them twice on the plain path
+    // Separate loops: sharing one loop body lets the compiler hoist half of the bit tests above the
+    // (wave-uniform) choice and pay for them twice on the plain path.
+    //
+    // Fast form (keys only, whole tile staged, full tiles): the slot is what a RETURNING LDS add on the
+    // running slot hands back.  The lanes of a digit's group then receive the group's slots in whatever
+    // order the LDS served them — on gfx950 that is ascending lane order (tools/probe/lds_order_probe.hip:
+    // 10^10 lane-rounds, no exception), i.e. the stable rank, but it is not a documented property, so it
+    // is not trusted: the source of pass p is sorted by the p digits below the current one, hence a
+    // group is in stable-equivalent order iff every key is >= the key in the slot before it on those
+    // low bits (any order among keys equal there is as good: later passes only look at higher digits).
+    // Each lane compares against the previous slot of its own round's group; a round that fails the
+    // test in any lane is redone with the ballots.  Pass 0 has no lower digits: any order will do.
+    if constexpr (STAGES == 1 && !HAS_V) {
+        if (!careful && full && (ablate & RDST_FAST_RANK) && !RDST_ABL(3)) {
+            const int low_bits = shift;  // key bits below the current digit
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                uint32_t* slot = &wh[digit_of(mk[i], shift)];
+                const uint32_t b = *slot;
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t r = atomicAdd(slot, SLOT_UNIT);
+                place(i, r);
+                if (low_bits) {
+                    const K prev = *reinterpret_cast<const K*>(reinterpret_cast<const unsigned char*>(s_keys) + r - SLOT_UNIT);
+                    const int up = (int)sizeof(K) * 8 - low_bits;
+                    const bool out_of_order = r != b && (K)(prev << up) > (K)(mk[i] << up);
+                    if (__builtin_amdgcn_ballot_w64(out_of_order) != 0 || (ablate & RDST_FAST_RANK_SELFTEST)) {  // never seen; keeps the pass exact regardless
+                        place(i, b + peers_below(digit_word<K>(mk[i], shift), bit0) * SLOT_UNIT);
+                    }
+                }
+            }
+            goto ranked;
+        }
+    }
     if (!careful) {
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
@@ -882,6 +915,7 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8,
         }
     }
 
+ranked:
     // 7. decoupled look-back over the earlier tiles (thread d walks digit d)
     __builtin_amdgcn_s_setprio(RDST_PRIO_LB);
     if (tid < RADIX) {
@@ -1112,7 +1146,7 @@ constexpr int default_cfg(uint32_t elem_bytes, uint64_t n) {
 // keys per thread for a key width, from the table's 8-byte figure: same bytes per thread
 constexpr int kpt_for(int kpt8, size_t elem_bytes) { return elem_bytes <= 4 ? kpt8 * 2 : (elem_bytes == 8 ? kpt8 : (kpt8 / 2) & ~1); }
 
-struct Tuning { int pass_cfg = -1; int hist_bpc = 0; bool profiling = false; bool chains = true; };  // pass_cfg < 0: default_cfg()
+struct Tuning { int pass_cfg = -1; int hist_bpc = 0; bool profiling = false; bool chains = true; int fast_rank = 1; };  // pass_cfg < 0: default_cfg()
 uint32_t g_ablate = 0;  // only ever set by the RDST_EXPERIMENTS build
 #ifdef RDST_EXPERIMENTS
 size_t g_exp_lds_total = 0;
@@ -1306,7 +1340,7 @@ int launch_pass_t(K* keys, K* tmp, uint64_t n, int level, const Layout& L, char*
     (void)cus;
     const dim3 grid((uint32_t)L.tiles), block(NWAVES * 64);  // >= one block per tile of any chain split
     hipLaunchKernelGGL((onesweep_kernel<K, S, KPT, NWAVES, STAGES, MAPPED, NARROW, V>), grid, block, lds, s, keys, tmp, vals, vtmp, n,
-                       level, cbase, status, status_near, chains, ticket, plan, err, (K)km.neg, (K)km.pos, g_ablate);
+                       level, cbase, status, status_near, chains, ticket, plan, err, (K)km.neg, (K)km.pos, g_ablate | (g_tuning.fast_rank ? RDST_FAST_RANK : 0u) | (g_tuning.fast_rank == 2 ? RDST_FAST_RANK_SELFTEST : 0u));
     HIP_TRY(hipGetLastError());
     return RDST_OK;
 }
@@ -1521,6 +1555,12 @@ int rdst_hip_set_tuning(int pass_config, int hist_blocks_per_cu) {
     if (pass_config >= kNumPassCfgs) return fail(RDST_ERR_ARG, "tuning value out of range");
     g_tuning.pass_cfg = pass_config >= 0 ? pass_config : -1;
     g_tuning.hist_bpc = hist_blocks_per_cu > 0 ? hist_blocks_per_cu : 0;
+    return RDST_OK;
+}
+
+int rdst_hip_set_fast_rank(int enabled) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    g_tuning.fast_rank = enabled == 2 ? 2 : (enabled != 0 ? 1 : 0);
     return RDST_OK;
 }
 

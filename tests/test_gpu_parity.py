@@ -83,6 +83,7 @@ def test_chain_split_shapes(gpu, dtype):
         "level 1 only two digits": (full & ~u.type(0xFE00)),
         "levels 0-1 constant": (full & ~u.type(0xFFFF)) | u.type(0x1234),
         "top levels only": full & (u.type(0xFF) << u.type(bits - 8)),
+        "uniform": full,
         "short": full[:40_000],
         "tiny": full[:700],
     }
@@ -93,6 +94,9 @@ def test_chain_split_shapes(gpu, dtype):
             for split in (True, False):
                 gpu.set_tuning(chain_split=split)
                 assert same_bits(_device_sort(gpu, a), exp), (dtype, name, split)
+            for fast in (0, 2):  # ballots only; returning-add ranking with every round sent through its fallback
+                gpu.set_tuning(fast_rank=fast)
+                assert same_bits(_device_sort(gpu, a), exp), (dtype, name, "fast_rank", fast)
     finally:
         gpu.set_tuning()
 

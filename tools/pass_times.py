@@ -25,8 +25,12 @@ if dt == "u32" and dist != "uniform":
 keys = torch.empty_like(src); tmp = torch.empty_like(src)
 ref = None
 cfgs = [int(x) for x in os.environ.get("RDST_CFGS", "-1").split(",")]
+vary = os.environ.get("RDST_VARY", "split")  # which knob the True/False column toggles: chain split or fast ranking
 for cfg, split in [(c, sp) for c in cfgs for sp in (True, False, True, False)]:
-    rs.set_tuning(cfg, 0, chain_split=split)
+    if vary == "fast":
+        rs.set_tuning(cfg, 0, chain_split=True, fast_rank=split)
+    else:
+        rs.set_tuning(cfg, 0, chain_split=split)
     rs.set_profiling(True)
     for it in range(4):
         keys.copy_(src)
