@@ -765,10 +765,14 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8,
     // digit are matched by ballots and its first lane adds the group's size.  Random keys: never.
     uint32_t uniform_rounds = 0;  // bit i: round i holds a single digit (wave-uniform value)
     bool careful = false;         // wave-uniform
+    constexpr bool CAN_FAST = STAGES == 1 && !HAS_V && TILE <= 65536;
+    uint32_t run_index[CAN_FAST ? (KPT + 1) / 2 : 1];  // fast ranking: index in the (wave, digit) run, 16-bit pairs
+    bool fast = false;                                // wave-uniform
     {
         const uint32_t d0 = digit_of(mk[0], shift);
         const uint32_t dn = (uint32_t)__builtin_amdgcn_mov_dpp((int)d0, 0x138, 0xf, 0xf, false);  // lane - 1's digit
         careful = __builtin_popcountll(__builtin_amdgcn_ballot_w64(d0 == dn) & ~1ull) >= 8;
+        if constexpr (CAN_FAST) fast = !careful && full && (ablate & RDST_FAST_RANK) && !RDST_ABL(3);
         if (careful) {
 #pragma unroll
             for (int i = 0; i < KPT; ++i) {
@@ -781,6 +785,15 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8,
                     const uint32_t below = peers_below_total(digit_word<K>(mk[i], shift), bit0, total);
                     if (below == 0) atomicAdd(&wh[d], total);
                 }
+            }
+        } else if (fast) {
+            // the count doubles as the ranking: the returning add hands every key its index inside the
+            // wave's run of its digit (step 5)
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                const uint32_t r = atomicAdd(&wh[digit_of(mk[i], shift)], 1u);
+                if (i & 1) run_index[i >> 1] |= r << 16;
+                else run_index[i >> 1] = r;
             }
         } else {
 #pragma unroll
@@ -854,35 +867,34 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8,
     // Separate loops: sharing one loop body lets the compiler hoist half of the bit tests above the
     // (wave-uniform) choice and pay for them twice on the plain path.
     //
-    // Fast form (keys only, whole tile staged, full tiles): the slot is what a RETURNING LDS add on the
-    // running slot hands back.  The lanes of a digit's group then receive the group's slots in whatever
-    // order the LDS served them — on gfx950 that is ascending lane order (tools/probe/lds_order_probe.hip:
-    // 10^10 lane-rounds, no exception), i.e. the stable rank, but it is not a documented property, so it
-    // is not trusted: the source of pass p is sorted by the p digits below the current one, hence a
-    // group is in stable-equivalent order iff every key is >= the key in the slot before it on those
-    // low bits (any order among keys equal there is as good: later passes only look at higher digits).
-    // Each lane compares against the previous slot of its own round's group; a round that fails the
-    // test in any lane is redone with the ballots.  Pass 0 has no lower digits: any order will do.
-    if constexpr (STAGES == 1 && !HAS_V) {
-        if (!careful && full && (ablate & RDST_FAST_RANK) && !RDST_ABL(3)) {
+    // Fast form (keys only, whole tile staged, full tiles): the counting pass of step 2 used a RETURNING
+    // LDS add, which handed every key its index inside the wave's run of its digit; the slot is the
+    // run's start plus that index, no second atomic.  The lanes of a digit's group received their
+    // indices in whatever order the LDS served them — on gfx950 that is ascending lane order
+    // (tools/probe/lds_order_probe.hip: 10^10 lane-rounds, no exception), i.e. the stable rank, but it
+    // is not a documented property, so it is not trusted: the source of pass p is sorted by the p
+    // digits below the current one, hence a run is in stable-equivalent order iff every key is >= the
+    // key in the slot before it on those low bits (any order among keys equal there is as good: later
+    // passes only look at higher digits).  Each lane compares against the slot before its own; if
+    // any lane of the wave fails, the wave's share of the tile is ranked again with the ballots.
+    // Pass 0 has no lower digits: any order will do.
+    if constexpr (CAN_FAST) {
+        if (fast) {
             const int low_bits = shift;  // key bits below the current digit
+            bool out_of_order = false;
 #pragma unroll
             for (int i = 0; i < KPT; ++i) {
-                uint32_t* slot = &wh[digit_of(mk[i], shift)];
-                const uint32_t b = *slot;
-                __builtin_amdgcn_wave_barrier();
-                const uint32_t r = atomicAdd(slot, SLOT_UNIT);
-                place(i, r);
+                const uint32_t idx = (i & 1) ? (run_index[i >> 1] >> 16) : (run_index[i >> 1] & 0xFFFFu);
+                const uint32_t sl = wh[digit_of(mk[i], shift)] + idx * SLOT_UNIT;  // start of the (wave, digit) run + index
+                place(i, sl);
                 if (low_bits) {
-                    const K prev = *reinterpret_cast<const K*>(reinterpret_cast<const unsigned char*>(s_keys) + r - SLOT_UNIT);
+                    const K prev = *reinterpret_cast<const K*>(reinterpret_cast<const unsigned char*>(s_keys) + sl - SLOT_UNIT);
                     const int up = (int)sizeof(K) * 8 - low_bits;
-                    const bool out_of_order = r != b && (K)(prev << up) > (K)(mk[i] << up);
-                    if (__builtin_amdgcn_ballot_w64(out_of_order) != 0 || (ablate & RDST_FAST_RANK_SELFTEST)) {  // never seen; keeps the pass exact regardless
-                        place(i, b + peers_below(digit_word<K>(mk[i], shift), bit0) * SLOT_UNIT);
-                    }
+                    out_of_order |= idx != 0 && (K)(prev << up) > (K)(mk[i] << up);
                 }
             }
-            goto ranked;
+            // never seen to fail; the ballot loop below redoes the wave's tile share if it ever does
+            if (__builtin_amdgcn_ballot_w64(out_of_order) == 0 && !(ablate & RDST_FAST_RANK_SELFTEST)) goto ranked;
         }
     }
     if (!careful) {
