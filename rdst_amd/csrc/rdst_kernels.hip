@@ -369,34 +369,44 @@ struct ScanArgs {
     uint32_t levels, allow_skip, level_lo, level_hi, hist_grid, tile, use_chains;
 };
 
-__global__ __launch_bounds__(256) void scan_kernel(ScanArgs a) {
-    __shared__ uint64_t s_scan[RADIX];
+constexpr int SCAN_GROUPS = 4;  // levels handled side by side, 256 threads (one per digit) each
+
+__global__ __launch_bounds__(256 * SCAN_GROUPS) void scan_kernel(ScanArgs a) {
+    __shared__ uint64_t s_wave_sum[SCAN_GROUPS][4];
     __shared__ uint32_t s_trivial[MAX_LEVELS];
     __shared__ uint32_t s_mode[MAX_LEVELS], s_skip[MAX_LEVELS];
-    __shared__ uint64_t s_seg[CHAINS + 1];
+    __shared__ uint64_t s_seg[SCAN_GROUPS][CHAINS + 1];
     __shared__ uint64_t s_group_start[MAX_LEVELS][CHAINS];  // bucket start of the first digit of each digit group
-    const int d = threadIdx.x;
-    if (d < MAX_LEVELS) s_trivial[d] = 0;
+    const int g = threadIdx.x / RADIX, d = threadIdx.x % RADIX, lane = d & 63, wv = d >> 6;
+    if (threadIdx.x < MAX_LEVELS) s_trivial[threadIdx.x] = 0;
     __syncthreads();
-    for (uint32_t l = 0; l < a.levels; ++l) {
+    for (uint32_t l0 = 0; l0 < a.levels; l0 += SCAN_GROUPS) {
+        const uint32_t l = l0 + (uint32_t)g;
+        const bool on = l < a.levels;
         uint64_t total = 0;
-        for (int r = 0; r < CHAINS; ++r) total += a.hpos[((size_t)l * CHAINS + r) * RADIX + d];
-        a.hist[(size_t)l * RADIX + d] = total;
-        if (total == a.n) s_trivial[l] = 1;
-        // Hillis-Steele inclusive scan over 256 u64 values
-        s_scan[d] = total;
-        __syncthreads();
-        for (int o = 1; o < RADIX; o <<= 1) {
-            const uint64_t y = (d >= o) ? s_scan[d - o] : 0;
-            __syncthreads();
-            s_scan[d] += y;
-            __syncthreads();
+        if (on) {
+            for (int r = 0; r < CHAINS; ++r) total += a.hpos[((size_t)l * CHAINS + r) * RADIX + d];
+            a.hist[(size_t)l * RADIX + d] = total;
+            if (total == a.n) s_trivial[l] = 1;
         }
-        a.base[(size_t)l * RADIX + d] = s_scan[d] - total;
-        if (d % (RADIX / CHAINS) == 0) s_group_start[l][d / (RADIX / CHAINS)] = s_scan[d] - total;
+        // inclusive scan over the group's 256 totals: shuffles inside a wave, then the waves' sums
+        uint64_t incl = total;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint64_t y = __shfl_up(incl, o);
+            if (lane >= o) incl += y;
+        }
+        if (lane == 63) s_wave_sum[g][wv] = incl;
+        __syncthreads();
+        uint64_t excl = incl - total;
+        for (int w = 0; w < wv; ++w) excl += s_wave_sum[g][w];
+        if (on) {
+            a.base[(size_t)l * RADIX + d] = excl;
+            if (d % (RADIX / CHAINS) == 0) s_group_start[l][d / (RADIX / CHAINS)] = excl;
+        }
         __syncthreads();
     }
-    if (d == 0) {
+    if (threadIdx.x == 0) {
         uint32_t in_tmp = 0, executed = 0;
         int prev = -1;  // last executed level
         const bool already_sorted = a.allow_skip && *a.inversion == 0;  // nothing to do at all
@@ -417,30 +427,31 @@ __global__ __launch_bounds__(256) void scan_kernel(ScanArgs a) {
         a.plan->executed = executed;
     }
     __syncthreads();
-    for (uint32_t l = 0; l < a.levels; ++l) {
-        if (s_skip[l]) continue;  // uniform
-        const uint32_t mode = s_mode[l];
+    for (uint32_t l0 = 0; l0 < a.levels; l0 += SCAN_GROUPS) {
+        const uint32_t l = l0 + (uint32_t)g;
+        const bool on = l < a.levels && !s_skip[l];
+        const uint32_t mode = on ? s_mode[l] : CHAIN_ONE;
         LevelChains* lc = a.chains + l;
-        if (d <= CHAINS) {
+        if (on && d <= CHAINS) {
             uint64_t lo;
             if (d == CHAINS) lo = a.n;
             else if (mode == CHAIN_POS) lo = (uint64_t)hist_first_block((uint32_t)d, a.hist_grid) * a.hist_piece;
             else if (mode == CHAIN_PAIR) lo = s_group_start[l - 1][d];
             else lo = d == 0 ? 0 : a.n;
-            s_seg[d] = lo < a.n ? lo : a.n;
+            s_seg[g][d] = lo < a.n ? lo : a.n;
         }
         __syncthreads();
-        if (d == 0) {
+        if (on && d == 0) {
             uint32_t row = 0;
             for (int c = 0; c < CHAINS; ++c) {
-                const uint64_t lo = s_seg[c], hi = s_seg[c + 1];
+                const uint64_t lo = s_seg[g][c], hi = s_seg[g][c + 1];
                 lc->seg_lo[c] = lo;
                 const uint32_t nt = hi > lo ? (uint32_t)((hi - (lo & ~(uint64_t)(TILE_ALIGN - 1)) + a.tile - 1) / a.tile) : 0u;
                 lc->ntiles[c] = nt;
                 lc->row0[c] = row;
                 row += nt;
             }
-            lc->seg_lo[CHAINS] = s_seg[CHAINS];
+            lc->seg_lo[CHAINS] = s_seg[g][CHAINS];
             lc->total_tiles = row;
             // walkers of such a chain skip the L2-resident copy of the status rows: most of its
             // tiles are written on other XCDs
@@ -451,15 +462,16 @@ __global__ __launch_bounds__(256) void scan_kernel(ScanArgs a) {
             }
             a.tickets[(size_t)l * TICKET_ROW + CHAINS * TICKET_STRIDE] = empty;
         }
-        // chain c's first destination of digit d
-        uint64_t acc = a.base[(size_t)l * RADIX + d];
-        for (int c = 0; c < CHAINS; ++c) {
-            a.cbase[((size_t)l * CHAINS + c) * RADIX + d] = acc;
-            uint64_t cnt;
-            if (mode == CHAIN_POS) cnt = a.hpos[((size_t)l * CHAINS + c) * RADIX + d];
-            else if (mode == CHAIN_PAIR) cnt = a.hpair[((size_t)l * CHAINS + c) * RADIX + d];
-            else cnt = c == 0 ? a.hist[(size_t)l * RADIX + d] : 0;
-            acc += cnt;
+        if (on) {  // chain c's first destination of digit d
+            uint64_t acc = a.base[(size_t)l * RADIX + d];
+            for (int c = 0; c < CHAINS; ++c) {
+                a.cbase[((size_t)l * CHAINS + c) * RADIX + d] = acc;
+                uint64_t cnt;
+                if (mode == CHAIN_POS) cnt = a.hpos[((size_t)l * CHAINS + c) * RADIX + d];
+                else if (mode == CHAIN_PAIR) cnt = a.hpair[((size_t)l * CHAINS + c) * RADIX + d];
+                else cnt = c == 0 ? a.hist[(size_t)l * RADIX + d] : 0;
+                acc += cnt;
+            }
         }
         __syncthreads();
     }
@@ -1434,10 +1446,14 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     const size_t status_hi = L.off_status + (size_t)L.status_bytes * level_hi * L.tiles * RADIX;
     if (g_tuning.profiling) D->prof_runs.push_back({D->prof_used, 0});
     if ((rc = prof_mark(*D, s))) return rc;
-    HIP_TRY(hipMemsetAsync(ws, 0, L.off_status, s));
-    if (status_hi > status_lo) {
-        HIP_TRY(hipMemsetAsync(ws + status_lo, 0, status_hi - status_lo, s));
-        HIP_TRY(hipMemsetAsync(ws + status_lo + (L.off_status_near - L.off_status), 0, status_hi - status_lo, s));
+    if (level_lo == 0 && level_hi == (uint32_t)LEVELS) {
+        HIP_TRY(hipMemsetAsync(ws, 0, L.zero_bytes, s));  // header, count tables and both copies of the status rows are contiguous
+    } else {
+        HIP_TRY(hipMemsetAsync(ws, 0, L.off_status, s));
+        if (status_hi > status_lo) {
+            HIP_TRY(hipMemsetAsync(ws + status_lo, 0, status_hi - status_lo, s));
+            HIP_TRY(hipMemsetAsync(ws + status_lo + (L.off_status_near - L.off_status), 0, status_hi - status_lo, s));
+        }
     }
     if ((rc = prof_mark(*D, s))) return rc;
 
@@ -1446,6 +1462,12 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     const uint64_t per_block_min = (uint64_t)HIST_THREADS * (16 / sizeof(K)) * 4;
     const uint64_t max_useful = (n + per_block_min - 1) / per_block_min;
     if (blocks > max_useful) blocks = max_useful;
+    // Every block pays for zeroing and folding 128 KiB of LDS and for ~7 000 global adds on shared
+    // addresses (measured: ~8 us + 0.2 us per block), against ~20 GB/s of sweep per block: below a few
+    // hundred MB the best block count is about sqrt(bytes / 4 KiB), not one per CU.
+    uint64_t balanced = 1;
+    while (balanced * balanced * 4096 < n * sizeof(K)) ++balanced;
+    if (blocks > balanced) blocks = balanced;
     if (blocks < 1) blocks = 1;
     unsigned long long* hpos = reinterpret_cast<unsigned long long*>(ws + L.off_hpos);
     uint32_t* inversion = reinterpret_cast<uint32_t*>(ws + L.off_err) + 1;  // second word of the (cleared) header
@@ -1475,7 +1497,7 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     sa.hist_grid = (uint32_t)blocks;
     sa.tile = L.tile;
     sa.use_chains = g_tuning.chains ? 1u : 0u;
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(256), 0, s, sa);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(256 * SCAN_GROUPS), 0, s, sa);
     HIP_TRY(hipGetLastError());
     if ((rc = prof_mark(*D, s))) return rc;
     for (uint32_t level = level_lo; level < level_hi; ++level) {
