@@ -1,0 +1,59 @@
+"""Development aid: randomized stress of the device sort against torch.sort (sizes, types, distributions,
+tuning modes).  Prints one line per failure and a summary."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import rdst_amd
+from rdst_amd import radix_sort as rs
+
+torch.manual_seed(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+budget = float(sys.argv[2]) if len(sys.argv) > 2 else 120.0
+g = torch.Generator(device="cuda"); g.manual_seed(torch.initial_seed())
+types = [("uint32", torch.int32), ("int32", torch.int32), ("float32", torch.int32), ("uint64", torch.int64), ("int64", torch.int64),
+         ("float64", torch.int64), ("uint16", torch.int16), ("uint8", torch.int8)]
+
+
+def mapped(x, name):  # signed-comparable image of rdst's key order
+    mn = torch.iinfo(x.dtype).min
+    if name.startswith("uint"): return x ^ mn
+    if name.startswith("int"): return x
+    return torch.where(x < 0, ~x ^ mn, x)
+
+
+def gen(n, it, kind):
+    info = torch.iinfo(it)
+    r = torch.randint(info.min, info.max, (n,), dtype=it, device="cuda", generator=g)
+    bits = info.bits
+    if kind == 1: r &= (1 << (bits // 2)) - 1                      # upper half zero
+    elif kind == 2: r = (r >> (bits // 2)) << (bits // 2)           # lower half zero
+    elif kind == 3: r = torch.cat([r[: n // 2] & 0xFFFF, (r[n // 2:] >> 16) << 16]) if bits >= 32 else r
+    elif kind == 4: r &= ~0xE0                                      # low byte in one digit group
+    elif kind == 5: r = r & ~0xFF00 | 0x4200 if bits >= 16 else r   # level 1 constant
+    elif kind == 6: r = r.sort().values                             # sorted as integers
+    elif kind == 7: r &= 0x0F0F0F0F if bits == 32 else r            # 16 values per digit
+    return r.contiguous()
+
+
+t0, runs, fails = time.time(), 0, 0
+while time.time() - t0 < budget:
+    name, it = types[int(torch.randint(0, len(types), (1,)))]
+    e = float(torch.rand(1)) * 7.4
+    n = max(1, int(10 ** e))
+    if torch.iinfo(it).bits == 64: n = min(n, 12_000_000)
+    kind = int(torch.randint(0, 8, (1,)))
+    split, fast = bool(torch.randint(0, 2, (1,))), int(torch.randint(0, 3, (1,)))
+    rs.set_tuning(chain_split=split, fast_rank=fast)
+    src = gen(n, it, kind)
+    keys = src.clone()
+    view = keys.view(getattr(torch, name))
+    rs.sort_device_tensor(view)
+    m = mapped(keys, name)
+    exp = mapped(src, name).sort().values
+    ok = bool((m == exp).all())
+    runs += 1
+    if not ok:
+        fails += 1
+        print(f"FAIL {name} n={n} kind={kind} split={split} fast={fast}", flush=True)
+    del src, keys, m, exp
+rs.set_tuning()
+print(f"stress: {runs} sorts, {fails} failures", flush=True)
