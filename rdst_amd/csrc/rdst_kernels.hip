@@ -57,7 +57,10 @@ constexpr uint32_t SPIN_LIMIT = 1u << 22;
 #define RDST_PRIO_LOAD 2
 #endif
 #ifndef RDST_PRIO_LB
-#define RDST_PRIO_LB 0
+#define RDST_PRIO_LB 3
+#endif
+#ifndef RDST_PRIO_SCAN
+#define RDST_PRIO_SCAN 3  // digit sums, tile scan, look-back: the four waves the block's other eight wait for
 #endif
 #ifndef RDST_PRIO_SCATTER
 #define RDST_PRIO_SCATTER 2
@@ -502,6 +505,8 @@ __global__ __launch_bounds__(256 * SCAN_GROUPS) void scan_kernel(ScanArgs a) {
 
 #ifdef RDST_EXPERIMENTS
 __device__ uint32_t* g_exp_stats = nullptr;  // [tiles][4] look-back records of pass 0 (tools/ only)
+__device__ uint32_t* g_exp_timeline = nullptr;  // [tiles][12] shader-clock stamps of thread 0 along a tile of pass 0
+#define RDST_STAMP(k) do { if (tl_on) tl[k] = (uint32_t)__builtin_amdgcn_s_memtime(); } while (0)
 #endif
 
 // lanes below me holding my digit, 4 VALU per bit: my bit as a 0 / -1 mask (v_bfe_i32), the
@@ -643,6 +648,12 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8,
 #define RDST_ABL(bit) (((ablate) >> (bit)) & 1u)
 #else
 #define RDST_ABL(bit) false
+#define RDST_STAMP(k) do {} while (0)
+#endif
+#ifdef RDST_EXPERIMENTS
+    uint32_t tl[12];
+    const bool tl_on = g_exp_timeline != nullptr && level == 0 && threadIdx.x == 0;
+    RDST_STAMP(0);
 #endif
     constexpr int BLOCK = NWAVES * 64;
     constexpr int TILE = BLOCK * KPT;
@@ -686,7 +697,8 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // Wave priority: the phases that issue memory traffic (the tile's loads, the look-back, the
     // scatter) go ahead of other waves' arithmetic (counting, ranking), so the memory pipeline is fed
-    // while the vector ALU works through the ranking of the CU's other block.  A/B: pass 1.84 -> 1.75 ms.
+    // while the vector ALU works through the ranking of the CU's other block (A/B: pass 1.84 -> 1.75 ms);
+    // so do the short serial stretches of the first four waves (digit sums, tile scan, look-back).
     __builtin_amdgcn_s_setprio(RDST_PRIO_LOAD);
     if (tid == 0) {
         // The chain's table entries and the mask of chains already handed out are requested before
@@ -725,6 +737,7 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8,
         s_begin[1] = valid;
     }
     __syncthreads();
+    RDST_STAMP(1);
     const uint32_t t = s_misc[0];  // tile index inside its chain
     if (t == ~0u) return;          // every chain is handed out
     const uint32_t chain = s_misc[2];
@@ -776,6 +789,7 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8,
         }
     }
 
+    RDST_STAMP(2);
     __builtin_amdgcn_s_setprio(0);
     // 2. per-wave 256-bin histogram in LDS ("early counts")
     uint32_t* wh = wave_hist + wave * RADIX;
@@ -823,8 +837,11 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8,
             for (int i = 0; i < KPT; ++i) atomicAdd(&wh[digit_of(mk[i], shift)], 1u);
         }
     }
+    RDST_STAMP(3);
     __syncthreads();
+    RDST_STAMP(4);
 
+    if (tid < RADIX) __builtin_amdgcn_s_setprio(RDST_PRIO_SCAN);  // the four waves every other wave of the block waits for
     // 3. thread d: digit count over the block's waves; publish the tile aggregate at once
     uint32_t cw[NWAVES];
     uint32_t count_d = 0, pub = 0;
@@ -869,7 +886,9 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8,
         }
     }
     __syncthreads();
+    RDST_STAMP(5);
 
+    __builtin_amdgcn_s_setprio(0);
     // 5. stable rank inside the wave: lanes with my digit and a lower lane id go first; rounds
     //    go in order.  The running slot of (wave, digit) lives in LDS: every lane reads it, then
     //    every lane adds one (LDS operations of one wave execute in program order), so after the
@@ -957,6 +976,7 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8,
     }
 
 ranked:
+    RDST_STAMP(6);
     // 7. decoupled look-back over the earlier tiles (thread d walks digit d)
     __builtin_amdgcn_s_setprio(RDST_PRIO_LB);
     if (tid < RADIX) {
@@ -985,7 +1005,9 @@ ranked:
         if constexpr (NARROW) s_delta[tid] = (uint32_t)first * (uint32_t)sizeof(K);
         else s_delta[tid] = first;
     }
+    RDST_STAMP(7);
     __syncthreads();
+    RDST_STAMP(8);
     if (s_misc[1]) return;  // never store with an unknown prefix
     __builtin_amdgcn_s_setprio(RDST_PRIO_SCATTER);
     if constexpr (FAR_X4) {
@@ -1063,6 +1085,15 @@ ranked:
     }
     // cannot happen with consistent counts; the range test keeps a logic error from faulting
     if (bad) atomicOr(err, ERR_SCATTER_RANGE);
+#ifdef RDST_EXPERIMENTS
+    RDST_STAMP(9);
+    if (tl_on) {
+        uint32_t* rec = g_exp_timeline + (size_t)(chain_row0 + t) * 12;
+        for (int k = 0; k < 10; ++k) rec[k] = tl[k];
+        rec[10] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));  // XCC_ID
+        rec[11] = blockIdx.x;
+    }
+#endif
 #undef RDST_ABL
 }
 
@@ -1632,6 +1663,23 @@ int rdst_hip_set_chain_split(int enabled) {
 int rdst_hip_exp_set_ablation(uint32_t mask) { g_ablate = mask; return 0; }
 int rdst_hip_exp_set_lds(uint32_t bytes) { g_exp_lds_total = bytes; return 0; }
 // per-tile look-back records of level 0: windows fetched, blocked re-polls, tiles consumed, shader clocks
+int rdst_hip_exp_timeline(uint32_t* host_out, uint64_t tiles) {
+    static uint32_t* dev = nullptr;
+    static uint64_t cap = 0;
+    if (host_out == nullptr) {
+        if (cap < tiles) {
+            if (dev) (void)hipFree(dev);
+            if (hipMalloc((void**)&dev, tiles * 48) != hipSuccess) return -1;
+            cap = tiles;
+        }
+        if (hipMemset(dev, 0, tiles * 48) != hipSuccess) return -1;
+        return hipMemcpyToSymbol(HIP_SYMBOL(g_exp_timeline), &dev, sizeof dev) == hipSuccess ? 0 : -1;
+    }
+    if (hipDeviceSynchronize() != hipSuccess || !dev) return -1;
+    uint32_t* null_dev = nullptr;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_exp_timeline), &null_dev, sizeof null_dev);
+    return hipMemcpy(host_out, dev, tiles * 48, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
 int rdst_hip_exp_stats(uint32_t* host_out, uint64_t tiles) {
     static uint32_t* dev = nullptr;
     static uint64_t cap = 0;
