@@ -142,7 +142,10 @@ __device__ __forceinline__ void st_relaxed(S* p, S v) {
 // WORD to arrive whole, which a naturally aligned dword inside a 16-byte store does.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void st_far_x4(uint32_t* p, u32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    // s_nop: a VMEM store of more than 64 bits must not be followed at once by a VALU write to its data
+    // registers (a manually inserted wait state of the ISA; the compiler adds it for its own stores but
+    // cannot see into the asm — without it the key-value kernel overwrote the first word in flight)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 #ifndef RDST_FAR_X4
 #define RDST_FAR_X4 1

@@ -123,6 +123,27 @@ def test_key_value_pairs(gpu, dtype, vdtype):
         assert np.array_equal(tv.cpu().numpy(), vals[order]), (dtype, vdtype, n)
 
 
+@pytest.mark.parametrize("kdt,vdt", [("int32", "int32"), ("int32", "int64"), ("int64", "int32"), ("int64", "int64")])
+def test_key_value_pairs_many_tiles(gpu, kdt, vdt):
+    """10^7 pairs, every key / value width, several times: thousands of tiles in flight (this is where a missing
+    wait state after the 16-byte status store once corrupted look-back words; 2 M pairs never showed it)."""
+    import torch
+    n = 10_000_019
+    g = torch.Generator(device="cuda").manual_seed(11)
+    info = torch.iinfo(getattr(torch, kdt))
+    src = torch.randint(info.min, info.max, (n,), dtype=getattr(torch, kdt), device="cuda", generator=g)
+    ut = torch.uint32 if kdt == "int32" else torch.uint64
+    for _ in range(6):
+        keys = src.clone()
+        vals = torch.arange(n, dtype=getattr(torch, vdt), device="cuda")
+        gpu.sort_pairs_device_tensor(keys.view(ut), vals)
+        k = keys ^ info.min
+        assert bool((k[1:] >= k[:-1]).all())
+        assert bool((src[vals.long()] == keys).all())
+        same = keys[1:] == keys[:-1]
+        assert bool((vals[1:][same] > vals[:-1][same]).all())
+
+
 def test_records_sorted_by_a_key_field(gpu):
     """A slice of structs with a built-in key field (benches/struct_sort.rs:11-27): rows follow their key."""
     import torch
