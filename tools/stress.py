@@ -34,16 +34,29 @@ def gen(n, it, kind):
     return r.contiguous()
 
 
-t0, runs, fails = time.time(), 0, 0
+t0, runs, fails, total_keys, big = time.time(), 0, 0, 0, 0
 while time.time() - t0 < budget:
     name, it = types[int(torch.randint(0, len(types), (1,)))]
-    e = float(torch.rand(1)) * 7.4
+    e = 3.0 + float(torch.rand(1)) * 4.6
     n = max(1, int(10 ** e))
     if torch.iinfo(it).bits == 64: n = min(n, 12_000_000)
     kind = int(torch.randint(0, 8, (1,)))
+    total_keys += n; big += n > 1_000_000
     split, fast = bool(torch.randint(0, 2, (1,))), int(torch.randint(0, 3, (1,)))
     rs.set_tuning(chain_split=split, fast_rank=fast)
     src = gen(n, it, kind)
+    if torch.iinfo(it).bits >= 32 and int(torch.randint(0, 4, (1,))) == 0:  # a key-value sort now and then
+        vt = torch.int32 if int(torch.randint(0, 2, (1,))) else torch.int64
+        keys = src.clone(); vals = torch.arange(n, dtype=vt, device="cuda")
+        rs.sort_pairs_device_tensor(keys.view(getattr(torch, name)), vals)
+        m = mapped(keys, name)
+        okp = bool((m[1:] >= m[:-1]).all()) and bool((src[vals.long()] == keys).all())
+        runs += 1
+        if not okp:
+            fails += 1
+            print(f"FAIL pairs {name} {vt} n={n} kind={kind}", flush=True)
+        del keys, vals, m
+        continue
     keys = src.clone()
     view = keys.view(getattr(torch, name))
     rs.sort_device_tensor(view)
@@ -56,4 +69,4 @@ while time.time() - t0 < budget:
         print(f"FAIL {name} n={n} kind={kind} split={split} fast={fast}", flush=True)
     del src, keys, m, exp
 rs.set_tuning()
-print(f"stress: {runs} sorts, {fails} failures", flush=True)
+print(f"stress: {runs} sorts ({big} above 10^6 keys, {total_keys:.3e} keys in all), {fails} failures", flush=True)
