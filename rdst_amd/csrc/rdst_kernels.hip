@@ -1430,13 +1430,15 @@ int launch_pass_t(K* keys, K* tmp, uint64_t n, int level, const Layout& L, char*
 template <typename K, typename S, bool MAPPED, bool NARROW>
 int launch_pass_s(int cfg, K* keys, K* tmp, uint64_t n, int level, const Layout& L, char* ws, KeyMap km, int cus, hipStream_t s) {
     switch (cfg) {
+#ifdef RDST_EXPERIMENTS  // the two small shapes are measured in DESIGN.md and only built into the tools library
         case 0: return launch_pass_t<K, S, kpt_for(8, sizeof(K)), 8, 1, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, cus, s);
         case 1: return launch_pass_t<K, S, kpt_for(12, sizeof(K)), 8, 2, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, cus, s);
+#endif
         case 2: return launch_pass_t<K, S, kpt_for(12, sizeof(K)), 12, 2, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, cus, s);
         case 3: return launch_pass_t<K, S, kpt_for(14, sizeof(K)), 12, 2, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, cus, s);
         case 4: return launch_pass_t<K, S, kpt_for(11, sizeof(K)), 12, 1, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, cus, s);
     }
-    return fail(RDST_ERR_ARG, "bad pass config");
+    return fail(RDST_ERR_ARG, "pass config not built into this library (0 and 1 exist in the tools build only)");
 }
 
 template <typename K>
