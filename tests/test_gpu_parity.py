@@ -64,6 +64,20 @@ def test_sort_matches_oracle_over_sizes(gpu, oracle, dtype):
         assert same_bits(exp, reference_sorted(a))  # oracle vs independent numpy, same input
 
 
+@pytest.mark.parametrize("dtype", ["uint32", "float32", "uint64", "uint16"])
+def test_every_built_pass_shape(gpu, dtype):
+    """The scatter-kernel shapes the product library carries (two-stage 18 432 / 21 504-key tiles, whole-tile
+    16 896) each sort every key width, not only the one they are the default for."""
+    a = random_bits(1_500_007, dtype, seed=77).copy()
+    exp = reference_sorted(a)
+    try:
+        for cfg in (2, 3, 4):
+            gpu.set_tuning(pass_config=cfg)
+            assert same_bits(_device_sort(gpu, a), exp), (dtype, cfg)
+    finally:
+        gpu.set_tuning()
+
+
 @pytest.mark.parametrize("dtype", ["uint32", "uint64", "float32"])
 def test_chain_split_shapes(gpu, dtype):
     """Every pass splits its source into 8 segments with a look-back chain each (position ranges for
