@@ -186,7 +186,9 @@ int rdst_hip_set_chain_split(int enabled);
 /* Experiment knob: enabled == 0 ranks every round of a scatter pass with wave ballots; the default
  * takes the slots a returning LDS add hands out and falls back to the ballots for any round whose
  * result fails the in-kernel order test (rdst_kernels.hip, step 5).  enabled == 2: self-test mode, every
- * round is treated as failed and redone (exercises the fallback).  Results are identical in all modes. */
+ * round is treated as failed and redone (exercises the fallback).  Bit 3 (value 8) set: slices of at most
+ * one small tile also go through the general pipeline instead of the one-workgroup sort.  Results are
+ * identical in all modes. */
 int rdst_hip_set_fast_rank(int enabled);
 
 /* Per-kernel device timing for benchmarks.  While enabled, every pipeline (sort / hook call)

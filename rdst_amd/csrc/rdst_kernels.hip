@@ -1100,6 +1100,98 @@ ranked:
 #undef RDST_ABL
 }
 
+// ------------------------------------------------------------------------------------------
+// Small slices: the whole LSD sort in one workgroup.  Up to 64 KiB of keys live in registers
+// (wave-striped like a K3 tile) and are re-ordered through LDS once per level with K3's counting,
+// scan and ballot ranking; no workspace, no look-back, one launch (~5 us per level instead of the
+// ~80 us the general pipeline costs below a tile of input).  Slots past n hold the largest mapped
+// key: stable passes keep them behind every real key, and they are never stored.
+// (src/sorts/lsb_sort.rs:39-127 is the reference's own small-chunk sorter.)
+// ------------------------------------------------------------------------------------------
+constexpr int SMALL_WAVES = 16;
+constexpr int SMALL_THREADS = SMALL_WAVES * 64;
+constexpr int small_kpt(size_t key_bytes) { return key_bytes <= 4 ? 16 : (key_bytes == 8 ? 8 : 4); }
+
+template <typename K, int LEVELS, bool MAPPED>
+__global__ __launch_bounds__(SMALL_THREADS) void small_sort_kernel(K* __restrict__ keys, uint32_t n, K neg, K pos) {
+    constexpr int KPT = small_kpt(sizeof(K));
+    constexpr int TILE = SMALL_THREADS * KPT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* wave_hist = reinterpret_cast<uint32_t*>(smem);                        // [SMALL_WAVES][256]
+    uint32_t* s_sum = reinterpret_cast<uint32_t*>(smem + SMALL_WAVES * 1024);       // [4]
+    K* stage = reinterpret_cast<K*>(smem + SMALL_WAVES * 1024 + 16);                // [TILE]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // only as many rounds as the slice needs (a short slice would otherwise be mostly padding, all of it
+    // on one bin): key index = wave * 64 * rounds + round * 64 + lane
+    const int rounds = (int)((n + SMALL_THREADS - 1) / SMALL_THREADS);
+    const uint32_t live = (uint32_t)rounds * SMALL_THREADS;
+    const uint32_t wbase = (uint32_t)wave * 64u * (uint32_t)rounds + (uint32_t)lane;
+    K mk[KPT];
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+        const uint32_t idx = wbase + i * 64;
+        K v = (K) ~(K)0;
+        if (i < rounds && idx < n) {
+            v = keys[idx];
+            if constexpr (MAPPED) v = map_key<K>(v, neg, pos);
+        }
+        mk[i] = v;
+    }
+    uint32_t* wh = wave_hist + wave * RADIX;
+    for (int level = 0; level < LEVELS; ++level) {
+        const int shift = level * 8, bit0 = shift & 31;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wh[lane + 64 * j] = 0;
+#pragma unroll
+        for (int i = 0; i < KPT; ++i)
+            if (i < rounds) atomicAdd(&wh[digit_of(mk[i], shift)], 1u);
+        __syncthreads();
+        uint32_t cw[SMALL_WAVES], count_d = 0;
+        if (tid < RADIX) {
+#pragma unroll
+            for (int w = 0; w < SMALL_WAVES; ++w) { cw[w] = wave_hist[w * RADIX + tid]; count_d += cw[w]; }
+        }
+        const bool trivial = __syncthreads_or(tid < RADIX && count_d == live) != 0;  // one digit holds everything
+        if (trivial) continue;  // block-uniform; the tables are re-zeroed at the top
+        uint32_t incl = count_d;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(incl, o);
+            if (lane >= o) incl += y;
+        }
+        if (tid < RADIX && lane == 63) s_sum[wave] = incl;
+        __syncthreads();
+        if (tid < RADIX) {
+            uint32_t run = incl - count_d;
+            for (int w = 0; w < wave; ++w) run += s_sum[w];
+#pragma unroll
+            for (int w = 0; w < SMALL_WAVES; ++w) { wave_hist[w * RADIX + tid] = run; run += cw[w]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            if (i < rounds) {  // block-uniform
+                uint32_t* slot = &wh[digit_of(mk[i], shift)];
+                const uint32_t b = *slot;
+                const uint32_t below = peers_below(digit_word<K>(mk[i], shift), bit0);
+                __builtin_amdgcn_wave_barrier();
+                atomicAdd(slot, 1u);
+                stage[b + below] = mk[i];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < KPT; ++i)
+            if (i < rounds) mk[i] = stage[wbase + i * 64];
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+        const uint32_t idx = wbase + i * 64;
+        if (i < rounds && idx < n) keys[idx] = MAPPED ? unmap_key<K>(mk[i], neg, pos) : mk[i];
+    }
+}
+
 // result sits in tmp after an odd number of executed passes: copy back
 // (src/sorts/lsb_sort.rs:117-126)
 template <typename K, int VEC>
@@ -1228,7 +1320,7 @@ constexpr int default_cfg(uint32_t elem_bytes, uint64_t n) {
 // keys per thread for a key width, from the table's 8-byte figure: same bytes per thread
 constexpr int kpt_for(int kpt8, size_t elem_bytes) { return elem_bytes <= 4 ? kpt8 * 2 : (elem_bytes == 8 ? kpt8 : (kpt8 / 2) & ~1); }
 
-struct Tuning { int pass_cfg = -1; int hist_bpc = 0; bool profiling = false; bool chains = true; int fast_rank = 1; };  // pass_cfg < 0: default_cfg()
+struct Tuning { int pass_cfg = -1; int hist_bpc = 0; bool profiling = false; bool chains = true; int fast_rank = 1; bool small_sort = true; };  // pass_cfg < 0: default_cfg()
 uint32_t g_ablate = 0;  // only ever set by the RDST_EXPERIMENTS build
 #ifdef RDST_EXPERIMENTS
 size_t g_exp_lds_total = 0;
@@ -1490,6 +1582,26 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     DeviceState* D;
     int rc = current_device_state(&D);
     if (rc) return rc;
+    if constexpr (!HAS_V) {
+        // a slice of at most one small tile: the one-workgroup sort, in place, no workspace
+        if (g_tuning.small_sort && level_lo == 0 && level_hi == (uint32_t)LEVELS && allow_skip && copy_back && !layout_out &&
+            n <= (uint64_t)SMALL_THREADS * small_kpt(sizeof(K))) {
+            const KeyMap km = key_map_for(kind, sizeof(K));
+            const size_t lds = (size_t)SMALL_WAVES * 1024 + 16 + sizeof(K) * SMALL_THREADS * small_kpt(sizeof(K));
+            const bool mapped = km.neg != 0 || km.pos != 0;
+            static bool attr_set[2] = {false, false};
+            if (!attr_set[mapped]) {
+                const void* fn = mapped ? reinterpret_cast<const void*>(&small_sort_kernel<K, LEVELS, true>)
+                                        : reinterpret_cast<const void*>(&small_sort_kernel<K, LEVELS, false>);
+                HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                attr_set[mapped] = true;
+            }
+            if (mapped) hipLaunchKernelGGL((small_sort_kernel<K, LEVELS, true>), dim3(1), dim3(SMALL_THREADS), lds, s, keys, (uint32_t)n, (K)km.neg, (K)km.pos);
+            else hipLaunchKernelGGL((small_sort_kernel<K, LEVELS, false>), dim3(1), dim3(SMALL_THREADS), lds, s, keys, (uint32_t)n, (K)km.neg, (K)km.pos);
+            HIP_TRY(hipGetLastError());
+            return RDST_OK;
+        }
+    }
     int cfg = g_tuning.pass_cfg;
     if (cfg < 0 || cfg >= kNumPassCfgs) cfg = default_cfg(sizeof(K), n);
     const Layout L = make_layout(n, sizeof(K), LEVELS, cfg, HAS_V ? PAIR_WAVES * 64 * pair_kpt(sizeof(K), ValBytes<V>::value) : 0);
@@ -1654,7 +1766,8 @@ int rdst_hip_set_tuning(int pass_config, int hist_blocks_per_cu) {
 
 int rdst_hip_set_fast_rank(int enabled) {
     std::lock_guard<std::mutex> lock(g_mutex);
-    g_tuning.fast_rank = enabled == 2 ? 2 : (enabled != 0 ? 1 : 0);
+    g_tuning.fast_rank = (enabled & 3) == 2 ? 2 : ((enabled & 3) != 0 ? 1 : 0);
+    g_tuning.small_sort = (enabled & 8) == 0;  // bit 3: experiments send even the smallest slices through the general pipeline
     return RDST_OK;
 }
 

@@ -64,6 +64,35 @@ def test_sort_matches_oracle_over_sizes(gpu, oracle, dtype):
         assert same_bits(exp, reference_sorted(a))  # oracle vs independent numpy, same input
 
 
+@pytest.mark.parametrize("dtype", DTYPES + SMALL_DTYPES)
+def test_one_workgroup_sort_boundaries(gpu, dtype):
+    """Slices of at most 64 KiB are sorted by one workgroup in LDS (no workspace, no look-back): every round
+    count of that kernel, its size limit and the first size beyond it, random and degenerate inputs, and the
+    same inputs through the general pipeline."""
+    limit = 1024 * {1: 16, 2: 16, 4: 16, 8: 8}[np.dtype(dtype).itemsize]
+    sizes = [2, 63, 64, 65, 1023, 1024, 1025, 2048, 3000, limit // 2 + 1, limit - 1, limit, limit + 1]
+    for i, n in enumerate(sizes):
+        base = random_bits(n, dtype, seed=500 + i).copy()
+        for variant in ("random", "equal", "sorted", "reverse", "two values"):
+            a = base.copy()
+            if variant == "equal":
+                a[:] = a[0]
+            elif variant == "sorted":
+                a = reference_sorted(a)
+            elif variant == "reverse":
+                a = reference_sorted(a)[::-1].copy()
+            elif variant == "two values":
+                a[:] = np.where(np.arange(n) % 3 == 0, a[0], a[-1])
+            exp = reference_sorted(a)
+            assert same_bits(_device_sort(gpu, a), exp), (dtype, n, variant)
+            if variant == "random":
+                try:
+                    gpu.set_tuning(small_sort=False)
+                    assert same_bits(_device_sort(gpu, a), exp), (dtype, n, "general pipeline")
+                finally:
+                    gpu.set_tuning()
+
+
 @pytest.mark.parametrize("dtype", ["uint32", "float32", "uint64", "uint16"])
 def test_every_built_pass_shape(gpu, dtype):
     """The scatter-kernel shapes the product library carries (two-stage 18 432 / 21 504-key tiles, whole-tile
