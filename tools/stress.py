@@ -37,7 +37,7 @@ def gen(n, it, kind):
 t0, runs, fails, total_keys, big = time.time(), 0, 0, 0, 0
 while time.time() - t0 < budget:
     name, it = types[int(torch.randint(0, len(types), (1,)))]
-    e = 3.0 + float(torch.rand(1)) * 4.6
+    e = float(sys.argv[3]) + float(torch.rand(1)) * float(sys.argv[4]) if len(sys.argv) > 4 else 3.0 + float(torch.rand(1)) * 4.6
     n = max(1, int(10 ** e))
     if torch.iinfo(it).bits == 64: n = min(n, 12_000_000)
     kind = int(torch.randint(0, 8, (1,)))
