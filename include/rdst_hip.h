@@ -165,8 +165,8 @@ int rdst_hip_scatter_level(const void* dev_src, void* dev_dst, uint64_t len, uin
 /* Replaces `Tuner::pick_algorithm` (src/tuner.rs:33-35) for the stock tuners: pure
  * integer decision tables, host only.  counts has 256 entries (src/sorter.rs:67-76).
  * gpu_min_len is read only by RDST_TUNER_GPU.  For host slices the device route starts to win at
- * about 3·10^5 elements (allocation + PCIe both ways): RDST_GPU_MIN_LEN_HOST_SLICE. */
-#define RDST_GPU_MIN_LEN_HOST_SLICE 262144u  /* measured break-even of rdst_hip_sort against the CPU route, see INTEGRATION.md */
+ * about 7·10^4 elements (pool allocation + PCIe both ways): RDST_GPU_MIN_LEN_HOST_SLICE. */
+#define RDST_GPU_MIN_LEN_HOST_SLICE 65536u  /* measured break-even of rdst_hip_sort against the CPU route, see INTEGRATION.md */
 int rdst_pick_algorithm(int tuner_id, const rdst_tuning_params* p, const uint64_t counts[256],
                         uint64_t gpu_min_len);
 

@@ -1334,6 +1334,7 @@ struct DeviceState {
     void* ws = nullptr;
     size_t ws_bytes = 0;
     uint32_t* host_err = nullptr;  // pinned
+    hipStream_t host_stream = nullptr;  // the host entry points' own stream: created once (creating and destroying one per call cost ~0.1 ms)
     hipEvent_t last_done = nullptr;  // recorded after every enqueue that uses the workspace
     hipStream_t last_stream = nullptr;
     bool have_last = false;
@@ -1975,24 +1976,36 @@ int rdst_hip_sort(void* host_data, uint64_t len, uint32_t elem_bytes, rdst_key_k
         HIP_TRY(hipSetDevice(opts->device));
     }
     const size_t bytes = (size_t)len * elem_bytes;
-    void *d_keys = nullptr, *d_tmp = nullptr;
+    const size_t half = align_up(bytes, 256);
+    // one stream-ordered allocation for keys + tmp from the device's pool (hipMalloc / hipFree pairs and a
+    // stream per call were most of the 0.55 ms this entry point cost on small slices)
     hipStream_t s = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_mutex);
+        DeviceState* D;
+        rc = current_device_state(&D);
+        if (rc == RDST_OK && !D->host_stream) {
+            hipError_t e0 = hipStreamCreateWithFlags(&D->host_stream, hipStreamNonBlocking);
+            if (e0 != hipSuccess) rc = fail(RDST_ERR_HIP, "hipStreamCreate", e0);
+        }
+        if (rc == RDST_OK) s = D->host_stream;
+    }
+    if (rc != RDST_OK) { if (prev_dev >= 0) (void)hipSetDevice(prev_dev); return rc; }
+    void* d_buf = nullptr;
     auto cleanup = [&]() {
-        if (d_keys) (void)hipFree(d_keys);
-        if (d_tmp) (void)hipFree(d_tmp);
-        if (s) (void)hipStreamDestroy(s);
+        if (d_buf) (void)hipFreeAsync(d_buf, s);
         if (prev_dev >= 0) (void)hipSetDevice(prev_dev);
     };
     hipError_t e;
-    if ((e = hipStreamCreate(&s)) != hipSuccess) { cleanup(); return fail(RDST_ERR_HIP, "hipStreamCreate", e); }
-    if ((e = hipMalloc(&d_keys, bytes)) != hipSuccess) { cleanup(); return fail(RDST_ERR_HIP, "hipMalloc(keys)", e); }
-    if ((e = hipMalloc(&d_tmp, bytes)) != hipSuccess) { cleanup(); return fail(RDST_ERR_HIP, "hipMalloc(tmp)", e); }
-    if ((e = hipMemcpyAsync(d_keys, host_data, bytes, hipMemcpyHostToDevice, s)) != hipSuccess) { cleanup(); return fail(RDST_ERR_HIP, "H2D", e); }
+    if ((e = hipMallocAsync(&d_buf, 2 * half, s)) != hipSuccess) { d_buf = nullptr; cleanup(); return fail(RDST_ERR_HIP, "hipMallocAsync(keys + tmp)", e); }
+    void* d_keys = d_buf;
+    void* d_tmp = static_cast<char*>(d_buf) + half;
+    if ((e = hipMemcpyAsync(d_keys, host_data, bytes, hipMemcpyHostToDevice, s)) != hipSuccess) { (void)hipStreamSynchronize(s); cleanup(); return fail(RDST_ERR_HIP, "H2D", e); }
     rc = rdst_hip_sort_device(d_keys, d_tmp, len, elem_bytes, kind, levels, s);
     if (rc == RDST_OK) rc = rdst_hip_device_status(s);
     if (rc != RDST_OK) { (void)hipStreamSynchronize(s); cleanup(); return rc; }
     // the host buffer is written only now, after the device reported success
-    if ((e = hipMemcpyAsync(host_data, d_keys, bytes, hipMemcpyDeviceToHost, s)) != hipSuccess) { cleanup(); return fail(RDST_ERR_HIP, "D2H", e); }
+    if ((e = hipMemcpyAsync(host_data, d_keys, bytes, hipMemcpyDeviceToHost, s)) != hipSuccess) { (void)hipStreamSynchronize(s); cleanup(); return fail(RDST_ERR_HIP, "D2H", e); }
     if ((e = hipStreamSynchronize(s)) != hipSuccess) { cleanup(); return fail(RDST_ERR_HIP, "sync", e); }
     cleanup();
     return RDST_OK;

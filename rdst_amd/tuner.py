@@ -77,7 +77,7 @@ class SingleThreadedTuner(_TableTuner):
 #: measured break-even of the host entry point (allocation + H2D + sort + D2H) against the CPU route
 #: (tools/breakeven.py): what a shim that still has the CPU algorithms should pass as
 #: ``gpu_min_len``.  This package has no CPU route, so its own default stays 0.
-GPU_MIN_LEN_HOST_SLICE = 1 << 18
+GPU_MIN_LEN_HOST_SLICE = 1 << 16
 
 
 class GpuTuner(_TableTuner):
