@@ -1335,6 +1335,9 @@ struct DeviceState {
     size_t ws_bytes = 0;
     uint32_t* host_err = nullptr;  // pinned
     hipStream_t host_stream = nullptr;  // the host entry points' own stream: created once (creating and destroying one per call cost ~0.1 ms)
+    void* host_buf = nullptr;           // their device buffer (keys + tmp), kept and grown on demand
+    size_t host_buf_bytes = 0;
+    std::mutex host_mutex;              // one host-slice sort per device at a time (they share stream and buffer)
     hipEvent_t last_done = nullptr;  // recorded after every enqueue that uses the workspace
     hipStream_t last_stream = nullptr;
     bool have_last = false;
@@ -1977,38 +1980,43 @@ int rdst_hip_sort(void* host_data, uint64_t len, uint32_t elem_bytes, rdst_key_k
     }
     const size_t bytes = (size_t)len * elem_bytes;
     const size_t half = align_up(bytes, 256);
-    // one stream-ordered allocation for keys + tmp from the device's pool (hipMalloc / hipFree pairs and a
-    // stream per call were most of the 0.55 ms this entry point cost on small slices)
-    hipStream_t s = nullptr;
+    // Stream and device buffer (keys + tmp) are kept per device: hipMalloc / hipFree pairs and a stream
+    // per call were most of the 0.55 ms this entry point cost on small slices.  (A stream-ordered pool
+    // allocation per call was tried first: with the system HIP runtime a sort whose buffer the pool
+    // had just recycled read stale keys — test_cpp_mirror — so the buffer is plain hipMalloc memory.)
+    DeviceState* D = nullptr;
     {
         std::lock_guard<std::mutex> lock(g_mutex);
-        DeviceState* D;
         rc = current_device_state(&D);
-        if (rc == RDST_OK && !D->host_stream) {
-            hipError_t e0 = hipStreamCreateWithFlags(&D->host_stream, hipStreamNonBlocking);
-            if (e0 != hipSuccess) rc = fail(RDST_ERR_HIP, "hipStreamCreate", e0);
-        }
-        if (rc == RDST_OK) s = D->host_stream;
     }
     if (rc != RDST_OK) { if (prev_dev >= 0) (void)hipSetDevice(prev_dev); return rc; }
-    void* d_buf = nullptr;
-    auto cleanup = [&]() {
-        if (d_buf) (void)hipFreeAsync(d_buf, s);
-        if (prev_dev >= 0) (void)hipSetDevice(prev_dev);
-    };
+    std::lock_guard<std::mutex> host_lock(D->host_mutex);
+    auto done = [&](int code) { if (prev_dev >= 0) (void)hipSetDevice(prev_dev); return code; };
     hipError_t e;
-    if ((e = hipMallocAsync(&d_buf, 2 * half, s)) != hipSuccess) { d_buf = nullptr; cleanup(); return fail(RDST_ERR_HIP, "hipMallocAsync(keys + tmp)", e); }
-    void* d_keys = d_buf;
-    void* d_tmp = static_cast<char*>(d_buf) + half;
-    if ((e = hipMemcpyAsync(d_keys, host_data, bytes, hipMemcpyHostToDevice, s)) != hipSuccess) { (void)hipStreamSynchronize(s); cleanup(); return fail(RDST_ERR_HIP, "H2D", e); }
+    if (!D->host_stream && (e = hipStreamCreateWithFlags(&D->host_stream, hipStreamNonBlocking)) != hipSuccess)
+        return done(fail(RDST_ERR_HIP, "hipStreamCreate", e));
+    hipStream_t s = D->host_stream;
+    if (D->host_buf_bytes < 2 * half) {
+        if (D->host_buf) { (void)hipStreamSynchronize(s); (void)hipFree(D->host_buf); D->host_buf = nullptr; D->host_buf_bytes = 0; }
+        const size_t want = 2 * half < (size_t)(64u << 20) ? 2 * half + (2 * half) / 2 : 2 * half;  // head room for small slices only
+        if ((e = hipMalloc(&D->host_buf, want)) != hipSuccess) return done(fail(RDST_ERR_HIP, "hipMalloc(keys + tmp)", e));
+        D->host_buf_bytes = want;
+    }
+    void* d_keys = D->host_buf;
+    void* d_tmp = static_cast<char*>(D->host_buf) + half;
+    if ((e = hipMemcpyAsync(d_keys, host_data, bytes, hipMemcpyHostToDevice, s)) != hipSuccess) { (void)hipStreamSynchronize(s); return done(fail(RDST_ERR_HIP, "H2D", e)); }
     rc = rdst_hip_sort_device(d_keys, d_tmp, len, elem_bytes, kind, levels, s);
     if (rc == RDST_OK) rc = rdst_hip_device_status(s);
-    if (rc != RDST_OK) { (void)hipStreamSynchronize(s); cleanup(); return rc; }
+    if (rc != RDST_OK) { (void)hipStreamSynchronize(s); return done(rc); }
     // the host buffer is written only now, after the device reported success
-    if ((e = hipMemcpyAsync(host_data, d_keys, bytes, hipMemcpyDeviceToHost, s)) != hipSuccess) { (void)hipStreamSynchronize(s); cleanup(); return fail(RDST_ERR_HIP, "D2H", e); }
-    if ((e = hipStreamSynchronize(s)) != hipSuccess) { cleanup(); return fail(RDST_ERR_HIP, "sync", e); }
-    cleanup();
-    return RDST_OK;
+    if ((e = hipMemcpyAsync(host_data, d_keys, bytes, hipMemcpyDeviceToHost, s)) != hipSuccess) { (void)hipStreamSynchronize(s); return done(fail(RDST_ERR_HIP, "D2H", e)); }
+    if ((e = hipStreamSynchronize(s)) != hipSuccess) return done(fail(RDST_ERR_HIP, "sync", e));
+    if (D->host_buf_bytes > ((size_t)1 << 30)) {  // do not sit on gigabytes between calls
+        (void)hipFree(D->host_buf);
+        D->host_buf = nullptr;
+        D->host_buf_bytes = 0;
+    }
+    return done(RDST_OK);
 }
 
 int rdst_hip_sort_records(void* host_records, uint64_t len, uint32_t record_bytes, uint32_t key_offset, uint32_t key_bytes,
