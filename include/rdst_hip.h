@@ -98,7 +98,8 @@ typedef struct {
  * Sorts `len` elements of `elem_bytes` bytes in place, ascending in rdst's mapped-key
  * order.  Blocking.  len <= 1 is a no-op (radix_sort_builder.rs:151).  `levels` must
  * equal elem_bytes (RadixKey::LEVELS of every built-in type).  On failure the buffer
- * is untouched. */
+ * is untouched.  The library keeps one stream and one device buffer (keys + tmp, up to 1 GiB; larger ones
+ * are released on return) per device for this entry point; concurrent calls on a device serialise. */
 int rdst_hip_sort(void* host_data, uint64_t len, uint32_t elem_bytes, rdst_key_kind kind,
                   uint32_t levels, const rdst_hip_opts* opts);
 
@@ -186,10 +187,12 @@ int rdst_hip_set_chain_split(int enabled);
 /* Experiment knob: enabled == 0 ranks every round of a scatter pass with wave ballots; the default
  * takes the slots a returning LDS add hands out and falls back to the ballots for any round whose
  * result fails the in-kernel order test (rdst_kernels.hip, step 5).  enabled == 2: self-test mode, every
- * round is treated as failed and redone (exercises the fallback).  Bit 3 (value 8) set: slices of at most
- * one small tile also go through the general pipeline instead of the one-workgroup sort.  Results are
- * identical in all modes. */
+ * round is treated as failed and redone (exercises the fallback).  Results are identical in all modes. */
 int rdst_hip_set_fast_rank(int enabled);
+
+/* Experiment knob: enabled == 0 sends slices of at most 64 KiB of keys through the general pipeline too,
+ * instead of the one-workgroup LDS sort (the device twin of src/sorts/lsb_sort.rs:39-127).  Same results. */
+int rdst_hip_set_small_sort(int enabled);
 
 /* Per-kernel device timing for benchmarks.  While enabled, every pipeline (sort / hook call)
  * records HIP events on its own stream between its launches and appends one "run" to a

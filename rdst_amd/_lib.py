@@ -28,6 +28,7 @@ SYMBOLS = (
     "rdst_hip_set_tuning",
     "rdst_hip_set_chain_split",
     "rdst_hip_set_fast_rank",
+    "rdst_hip_set_small_sort",
     "rdst_hip_set_profiling",
     "rdst_hip_profile_runs",
     "rdst_hip_profile_run",
@@ -89,6 +90,7 @@ def load():
     lib.rdst_hip_set_tuning.argtypes = [ci, ci]
     lib.rdst_hip_set_chain_split.argtypes = [ci]
     lib.rdst_hip_set_fast_rank.argtypes = [ci]
+    lib.rdst_hip_set_small_sort.argtypes = [ci]
     lib.rdst_hip_set_profiling.argtypes = [ci]
     lib.rdst_hip_profile_run.argtypes = [ci, ctypes.POINTER(ctypes.c_float), u32, ctypes.POINTER(u32)]
     lib.rdst_hip_last_error.restype = ctypes.c_char_p

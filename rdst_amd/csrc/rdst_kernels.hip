@@ -1770,8 +1770,13 @@ int rdst_hip_set_tuning(int pass_config, int hist_blocks_per_cu) {
 
 int rdst_hip_set_fast_rank(int enabled) {
     std::lock_guard<std::mutex> lock(g_mutex);
-    g_tuning.fast_rank = (enabled & 3) == 2 ? 2 : ((enabled & 3) != 0 ? 1 : 0);
-    g_tuning.small_sort = (enabled & 8) == 0;  // bit 3: experiments send even the smallest slices through the general pipeline
+    g_tuning.fast_rank = enabled == 2 ? 2 : (enabled != 0 ? 1 : 0);
+    return RDST_OK;
+}
+
+int rdst_hip_set_small_sort(int enabled) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    g_tuning.small_sort = enabled != 0;
     return RDST_OK;
 }
 

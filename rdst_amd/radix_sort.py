@@ -341,7 +341,8 @@ def radix_sort_unstable(data, key=None) -> None:
 def set_tuning(pass_config=-1, hist_blocks_per_cu=0, chain_split=True, fast_rank=True, small_sort=True):
     _lib.check(_lib.load().rdst_hip_set_tuning(int(pass_config), int(hist_blocks_per_cu)))
     _lib.check(_lib.load().rdst_hip_set_chain_split(int(bool(chain_split))))
-    _lib.check(_lib.load().rdst_hip_set_fast_rank((2 if fast_rank == 2 else int(bool(fast_rank))) | (0 if small_sort else 8)))
+    _lib.check(_lib.load().rdst_hip_set_fast_rank(2 if fast_rank == 2 else int(bool(fast_rank))))
+    _lib.check(_lib.load().rdst_hip_set_small_sort(int(bool(small_sort))))
 
 
 def set_profiling(enabled: bool):
