@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RDST_HIP_ABI_VERSION 1
+#define RDST_HIP_ABI_VERSION 2
 
 /* Which built-in RadixKey mapping the element type uses (src/radix_key_impl.rs). */
 typedef enum {
@@ -84,6 +84,23 @@ typedef enum {
     RDST_TUNER_GPU = 3              /* StandardTuner, except depth-0 chunks >= gpu_min_len go to GPU_LSD */
 } rdst_tuner_id;
 
+/* What ran between two profiling marks (rdst_hip_profile_run_stages); a scatter pass carries its
+ * level in bits 8..15. */
+typedef enum {
+    RDST_STAGE_CLEAR = 1,    /* workspace clear */
+    RDST_STAGE_HIST = 2,     /* K1: every level's histogram (returns at once on the hybrid route) */
+    RDST_STAGE_SCAN = 3,     /* K2 */
+    RDST_STAGE_PASS = 4,     /* K3, one level (skipped levels return at once) */
+    RDST_STAGE_COPYBACK = 5,
+    RDST_STAGE_HIST16 = 6,   /* K1h: counts of the top 16 bits (hybrid route) */
+    RDST_STAGE_ROUTE = 7,    /* route decision + bucket starts */
+    RDST_STAGE_LOCAL = 8     /* K4: per-bucket sort of the remaining levels inside LDS (hybrid route) */
+} rdst_stage;
+
+/* Device routes (rdst_hip_last_route). */
+#define RDST_ROUTE_LSD 0u     /* one scatter pass per level */
+#define RDST_ROUTE_HYBRID 1u  /* two scatter passes on the top 16 bits + one in-LDS sort per bucket */
+
 /* Options of the host entry point.  NULL = defaults. */
 typedef struct {
     int32_t  device;       /* HIP device ordinal, -1 = current device */
@@ -135,8 +152,15 @@ int rdst_hip_sort_pairs_device(void* dev_keys, void* dev_vals, void* dev_tmp_key
                                uint32_t val_bytes, void* stream);
 
 /* Blocks until everything queued on `stream` by this library has finished and returns
- * RDST_ERR_DEVICE if any kernel raised the workspace error word since the last check. */
+ * RDST_ERR_DEVICE if any kernel raised the device error word since the last check.  The word is kept
+ * outside the per-sort workspace: an error raised by an earlier asynchronous sort is still reported after
+ * later sorts were enqueued, once; the check clears it. */
 int rdst_hip_device_status(void* stream);
+
+/* Test hook: ORs `bits` into the device error word from a one-thread kernel on `stream`, exactly as a failing
+ * sort kernel would.  The word is sticky: it survives later sorts and workspace growth until
+ * rdst_hip_device_status (or a blocking entry point) reports and clears it. */
+int rdst_hip_debug_raise_device_error(uint32_t bits, void* stream);
 
 /* Parity hook for get_counts_with_ends (src/sort_utils.rs:109-180) /
  * par_get_counts_with_ends (:35-106): 256-bin histogram of digit `level` over a
@@ -204,6 +228,20 @@ int rdst_hip_set_small_sort(int enabled);
 int rdst_hip_set_profiling(int enabled);
 int rdst_hip_profile_runs(void);
 int rdst_hip_profile_run(int run, float* out_ms, uint32_t capacity, uint32_t* n_out);
+/* The same run's stage codes, entry for entry (rdst_stage, a pass's level in bits 8..15): the hybrid route
+ * inserts RDST_STAGE_HIST16 and RDST_STAGE_ROUTE after the clear and RDST_STAGE_LOCAL after the passes. */
+int rdst_hip_profile_run_stages(int run, uint32_t* stages_out, uint32_t capacity, uint32_t* n_out);
+
+/* Route choice.  Whole sorts of 4- and 8-byte keys with min_len <= len <= 65 536 tiles count the top 16 bits
+ * of the keys first (K1h) and, when every one of the 65 536 buckets fits one tile of the in-LDS sort (K4),
+ * take the hybrid route — the device form of rdst's own MSD-then-Lsb route at this size (SURVEY.md §3.1;
+ * src/tuners/standard_tuner.rs:46-62 picks by length and counts, too).  enabled == 0: LSD route always.
+ * min_len == 0 keeps the built-in threshold (2^28).  Results are identical on either route.
+ * Not part of the reference surface. */
+int rdst_hip_set_hybrid(int enabled, uint64_t min_len);
+
+/* Route the most recent sort enqueued by this library on the current device took (RDST_ROUTE_*).  Blocks on `stream`. */
+int rdst_hip_last_route(void* stream, uint32_t* route_out);
 
 /* Last error message of the calling thread ("" if none). */
 const char* rdst_hip_last_error(void);

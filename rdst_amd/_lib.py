@@ -32,6 +32,10 @@ SYMBOLS = (
     "rdst_hip_set_profiling",
     "rdst_hip_profile_runs",
     "rdst_hip_profile_run",
+    "rdst_hip_profile_run_stages",
+    "rdst_hip_set_hybrid",
+    "rdst_hip_last_route",
+    "rdst_hip_debug_raise_device_error",
     "rdst_hip_last_error",
     "rdst_hip_abi_version",
 )
@@ -93,6 +97,10 @@ def load():
     lib.rdst_hip_set_small_sort.argtypes = [ci]
     lib.rdst_hip_set_profiling.argtypes = [ci]
     lib.rdst_hip_profile_run.argtypes = [ci, ctypes.POINTER(ctypes.c_float), u32, ctypes.POINTER(u32)]
+    lib.rdst_hip_profile_run_stages.argtypes = [ci, ctypes.POINTER(u32), u32, ctypes.POINTER(u32)]
+    lib.rdst_hip_set_hybrid.argtypes = [ci, u64]
+    lib.rdst_hip_last_route.argtypes = [vp, ctypes.POINTER(u32)]
+    lib.rdst_hip_debug_raise_device_error.argtypes = [u32, vp]
     lib.rdst_hip_last_error.restype = ctypes.c_char_p
     for name in SYMBOLS:
         if name not in ("rdst_hip_workspace_bytes", "rdst_hip_last_error"):

@@ -32,10 +32,13 @@
 #include <string.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <stddef.h>
 #include <mutex>
 #include <type_traits>
 #include <string>
 #include <vector>
+#include <map>
+#include <utility>
 
 #include "rdst_hip.h"
 
@@ -72,6 +75,19 @@ constexpr uint32_t RDST_FAST_RANK = 1u << 16;  // bit of the pass kernel's flag 
 constexpr uint32_t RDST_FAST_RANK_SELFTEST = 1u << 17;  // treat every round of the fast ranking as failed: exercises its fallback
 constexpr uint32_t ERR_LOOKBACK_TIMEOUT = 1;
 constexpr uint32_t ERR_SCATTER_RANGE = 2;  // a computed destination fell outside [0, n): never stored
+constexpr uint32_t ERR_LOCAL_OVERFLOW = 4;  // a bucket of the hybrid route larger than the local sort's tile: never sorted
+
+// Two routes through the kernels, chosen ON THE DEVICE from the counts of the key multiset — the device
+// form of Tuner::pick_algorithm(params, counts) (src/tuner.rs:33-35, src/sorter.rs:67-76):
+//   ROUTE_LSD     K1, K2, one K3 pass per level (k*(2L+1) bytes per key)
+//   ROUTE_HYBRID  the shape of rdst's own 10^9-key route (two MSD levels, then Lsb on
+//                 ~15 k-key chunks, src/sorts/lsb_sort.rs:39-127): K1h counts the top 16 bits, two K3
+//                 passes order the slice by them (levels L-2, L-1), and K4 sorts every one of the
+//                 65 536 buckets by the remaining levels inside LDS — one read and one coalesced write
+//                 instead of L-2 scatter passes (u32: 28 instead of 36 bytes per key; u64: 56 instead
+//                 of 136).  Taken when every bucket fits K4's tile; anything else goes the LSD way.
+constexpr uint32_t ROUTE_LSD = 0, ROUTE_HYBRID = 1;
+constexpr int H16_BINS = 65536;
 
 struct Plan {
     uint32_t skip[MAX_LEVELS];        // pass would move nothing (one bin holds every key)
@@ -79,6 +95,8 @@ struct Plan {
     uint32_t chain_mode[MAX_LEVELS];  // how the pass's source splits into look-back chains (CHAIN_*)
     uint32_t result_in_tmp;           // where the data sits after the last executed pass
     uint32_t executed;                // number of passes executed
+    uint32_t route;                   // ROUTE_LSD or ROUTE_HYBRID (decided on the device by route_kernel)
+    uint32_t local_sort;              // hybrid route and the slice is not already sorted: K4 runs
 };
 
 // Look-back chains.  One chain over all tiles makes every tile walk back over ~(status latency /
@@ -234,8 +252,10 @@ template <typename K, int LEVELS, int VEC, bool PAIR>
 __global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const K* __restrict__ keys, uint64_t n, K neg, K pos,
                                                             unsigned long long* __restrict__ hpos /* [LEVELS][CHAINS][256]: counts per position range */,
                                                             unsigned long long* __restrict__ hpair /* [LEVELS][CHAINS][256]: counts per group of the previous digit (PAIR) */,
-                                                            uint32_t* __restrict__ inversion /* set if keys[i-1] > keys[i] anywhere */) {
+                                                            uint32_t* __restrict__ inversion /* set if keys[i-1] > keys[i] anywhere */,
+                                                            const Plan* __restrict__ plan /* nullable: the hybrid route has its own counts (K1h) */) {
     using P = HistPlan<LEVELS, PAIR>;
+    if (plan && plan->route == ROUTE_HYBRID) return;
     constexpr int COPIES = P::COPIES, PCOPIES = P::PCOPIES, WORDS = P::WORDS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* s_h = reinterpret_cast<uint32_t*>(smem);
@@ -366,6 +386,202 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const K* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------
+// K1h: histogram of the TOP 16 BITS of the mapped key (65 536 buckets) from one read — what the
+// hybrid route needs: bucket sizes (does every bucket fit K4's tile?), bucket starts, and, summed
+// the right way, everything K2 wants for the two K3 passes on levels L-2 and L-1 (digit totals,
+// the per-position-range counts of level L-2, the (digit_{L-1}, group of digit_{L-2}) joint counts).
+// One LDS atomic per key.  Same sweep as K1 (same pieces, same inversion test).
+//
+// LDS: 65 536 16-bit counters, two per word (128 KiB).  A block counts up to n/grid keys, so a
+// counter can overflow on skewed input; a low half then carries into the high half, a high half
+// wraps.  Either way the DECODED counters sum to less than the keys the block has counted (a carry
+// loses 65 535, a wrap 65 536, nothing ever gains), so one block-wide sum at the end detects any
+// overflow exactly, at no cost per key — and a block with such a bucket could never have been on the
+// hybrid route anyway.  The flag sends the sort down the LSD route.
+// ------------------------------------------------------------------------------------------
+constexpr int H16_WORDS = H16_BINS / 2;
+
+template <typename K, int VEC, bool MAPPED>
+__global__ __launch_bounds__(HIST_THREADS) void hist16_kernel(const K* __restrict__ keys, uint64_t n, K neg, K pos,
+                                                              uint32_t* __restrict__ h16 /* [65536] bucket counts */,
+                                                              unsigned long long* __restrict__ hpos16 /* [CHAINS][256]: digit L-2 per position range */,
+                                                              uint32_t* __restrict__ inversion, uint32_t* __restrict__ overflow) {
+    constexpr int W = sizeof(K) * 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* s_h = reinterpret_cast<uint32_t*>(smem);
+    __shared__ unsigned long long s_sum;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < H16_WORDS; i += HIST_THREADS) s_h[i] = 0;
+    if (tid == 0) s_sum = 0;
+    __syncthreads();
+
+    constexpr uint64_t GRAN = (uint64_t)HIST_THREADS * VEC * 4;
+    const uint64_t piece = hist_piece(n, gridDim.x, GRAN);
+    const uint64_t p_begin = (uint64_t)blockIdx.x * piece;
+    uint64_t p_end = p_begin + piece;
+    if (p_end > n) p_end = n;
+
+    bool inv = false;
+    auto mapped = [&](K raw) -> K { return MAPPED ? map_key<K>(raw, neg, pos) : raw; };
+    auto count = [&](K raw, K before, bool careful) -> K {
+        const K m = mapped(raw);
+        inv |= before > m;
+        const uint32_t b = (uint32_t)(m >> (W - 16));
+        uint32_t* w = &s_h[b >> 1];
+        const uint32_t inc = 1u << ((b & 1u) * 16);
+        // sorted or low-entropy input puts a whole wave on one counter (64 serialised atomics): one lane adds then
+        if (careful && __all((int)(b == (uint32_t)__builtin_amdgcn_readfirstlane((int)b))) != 0) {
+            if ((tid & 63) == 0) atomicAdd(w, inc * 64u);
+        } else {
+            atomicAdd(w, inc);
+        }
+        return m;
+    };
+    auto mapped_at = [&](uint64_t idx) -> K { return idx == 0 ? (K)0 : mapped(keys[idx - 1]); };
+
+    struct alignas(sizeof(K) * VEC) V { K e[VEC]; };
+    uint64_t i = p_begin + (uint64_t)tid * VEC;
+    constexpr uint64_t STRIDE = (uint64_t)HIST_THREADS * VEC;
+    const uint64_t lane_rest = (uint64_t)(63 - (tid & 63)) * VEC;
+    for (; i + lane_rest + 3 * STRIDE + VEC <= p_end; i += 4 * STRIDE) {
+        V v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const V*>(keys + i + u * STRIDE);
+        K edge[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) edge[u] = ((tid & 63) == 0 && i + u * STRIDE > 0) ? keys[i + u * STRIDE - 1] : (K)0;
+        const uint32_t b0 = (uint32_t)(mapped(v[0].e[0]) >> (W - 16));
+        const bool careful = __all((int)(b0 == (uint32_t)__builtin_amdgcn_readfirstlane((int)b0))) != 0;
+        auto batch = [&](bool c) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                K before = lane_below<K>(mapped(v[u].e[VEC - 1]));
+                if ((tid & 63) == 0) before = (i + u * STRIDE > 0) ? mapped(edge[u]) : (K)0;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) before = count(v[u].e[e], before, c);
+            }
+        };
+        if (careful) batch(true);
+        else batch(false);
+    }
+    for (; i < p_end; i += STRIDE) {
+        K before = mapped_at(i);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+            if (i + e < p_end) before = count(keys[i + e], before, false);
+    }
+    if (inv) atomicOr(inversion, 1u);
+    __syncthreads();
+
+    // fold into the global table; the decoded counters must add up to the keys of the piece
+    unsigned long long local = 0;
+    for (int w = tid; w < H16_WORDS; w += HIST_THREADS) {
+        const uint32_t v = s_h[w];
+        const uint32_t lo = v & 0xFFFFu, hi = v >> 16;
+        local += lo + hi;
+        if (lo) atomicAdd(&h16[2 * w], lo);
+        if (hi) atomicAdd(&h16[2 * w + 1], hi);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
+    if ((tid & 63) == 0) atomicAdd(&s_sum, local);
+    // digit L-2 (the low byte of the bucket index) of this piece, for its position range's table
+    {
+        const int d = tid & 255, q = tid >> 8;  // four threads per digit, 64 values of the high byte each
+        uint32_t c = 0;
+        for (int h = q * 64; h < q * 64 + 64; ++h) {
+            const uint32_t v = s_h[h * 128 + (d >> 1)];
+            c += (d & 1) ? (v >> 16) : (v & 0xFFFFu);
+        }
+        const uint32_t range = hist_range_of(blockIdx.x, gridDim.x);
+        if (c) atomicAdd(&hpos16[(size_t)range * RADIX + d], (unsigned long long)c);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const uint64_t counted = p_end > p_begin ? p_end - p_begin : 0;
+        if (s_sum != counted) atomicOr(overflow, 1u);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Route decision + the hybrid route's tables: one block.  Thread t owns buckets [64t, 64t + 64), i.e.
+// high byte t / 4 and two digit groups of the low byte.  If no counter overflowed and the largest
+// bucket fits K4's tile: route = HYBRID, bucket starts (exclusive scan in bucket order = key order),
+// and the count tables K2 reads for levels L-2 and L-1 in the places K1 would have put them.
+// ------------------------------------------------------------------------------------------
+struct RouteArgs {
+    const uint32_t* h16;              // [65536]
+    const unsigned long long* hpos16; // [CHAINS][256]
+    const uint32_t* overflow;
+    uint32_t* bstart;                 // [65537] out
+    unsigned long long* hpos;         // [levels][CHAINS][256] (zeroed)
+    unsigned long long* hpair;        // [levels][CHAINS][256] (zeroed)
+    Plan* plan;
+    uint64_t n;
+    uint32_t levels, cap;
+};
+
+__global__ __launch_bounds__(1024) void route_kernel(RouteArgs a) {
+    __shared__ uint32_t s_wsum[16], s_wmax[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t c[64];
+    const uint4* src = reinterpret_cast<const uint4*>(a.h16) + (size_t)tid * 16;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const uint4 v = src[k];
+        c[4 * k] = v.x; c[4 * k + 1] = v.y; c[4 * k + 2] = v.z; c[4 * k + 3] = v.w;
+    }
+    uint32_t sum0 = 0, sum1 = 0, mx = 0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) { sum0 += c[k]; mx = c[k] > mx ? c[k] : mx; }
+#pragma unroll
+    for (int k = 32; k < 64; ++k) { sum1 += c[k]; mx = c[k] > mx ? c[k] : mx; }
+    const uint32_t mine = sum0 + sum1;
+    uint32_t incl = mine, wmax = mx;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(incl, o);
+        if (lane >= o) incl += y;
+        const uint32_t m = __shfl_xor(wmax, o);
+        wmax = m > wmax ? m : wmax;
+    }
+    if (lane == 63) s_wsum[wave] = incl;
+    if (lane == 0) s_wmax[wave] = wmax;
+    __syncthreads();
+    uint32_t excl = incl - mine, bmax = 0;
+    for (int w = 0; w < 16; ++w) {
+        if (w < wave) excl += s_wsum[w];
+        bmax = s_wmax[w] > bmax ? s_wmax[w] : bmax;
+    }
+    const bool hybrid = *a.overflow == 0 && bmax <= a.cap;
+    if (tid == 0) a.plan->route = hybrid ? ROUTE_HYBRID : ROUTE_LSD;
+    if (!hybrid) return;
+    uint32_t run = excl;
+    uint4* dst = reinterpret_cast<uint4*>(a.bstart) + (size_t)tid * 16;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        uint4 v;
+        v.x = run; run += c[4 * k];
+        v.y = run; run += c[4 * k + 1];
+        v.z = run; run += c[4 * k + 2];
+        v.w = run; run += c[4 * k + 3];
+        dst[k] = v;
+    }
+    if (tid == 1023) a.bstart[H16_BINS] = run;  // == n
+    const uint32_t top = a.levels - 1, dh = (uint32_t)tid >> 2, q = (uint32_t)tid & 3u;
+    // level L-1, pair counts: (digit dh, group of the level L-2 digit)
+    a.hpair[((size_t)top * CHAINS + 2 * q) * RADIX + dh] = sum0;
+    a.hpair[((size_t)top * CHAINS + 2 * q + 1) * RADIX + dh] = sum1;
+    // level L-1 totals go to range 0 (the pass runs second: its chains come from the pair counts)
+    uint32_t tot = mine;
+    tot += __shfl_xor(tot, 1);
+    tot += __shfl_xor(tot, 2);
+    if (q == 0) a.hpos[((size_t)top * CHAINS) * RADIX + dh] = tot;
+    // level L-2, per position range: as K1h counted them
+    for (int j = tid; j < CHAINS * RADIX; j += 1024) a.hpos[(size_t)(top - 1) * CHAINS * RADIX + j] = a.hpos16[j];
+}
+
+// ------------------------------------------------------------------------------------------
 // K2: one block of 256 threads.  Digit totals of every level (sum of the range tables), their
 // exclusive scan -> bucket start table, the skip plan, and for every executed level the chain
 // tables: segment bounds, tile counts, ticket order, and each chain's per-digit start
@@ -426,8 +642,12 @@ __global__ __launch_bounds__(256 * SCAN_GROUPS) void scan_kernel(ScanArgs a) {
         uint32_t in_tmp = 0, executed = 0;
         int prev = -1;  // last executed level
         const bool already_sorted = a.allow_skip && *a.inversion == 0;  // nothing to do at all
+        // hybrid route: only the two top levels are scatter passes, K4 does the rest
+        const bool hybrid = a.plan->route == ROUTE_HYBRID;
+        const uint32_t level_lo = hybrid ? a.levels - 2 : a.level_lo;
+        a.plan->local_sort = hybrid && !already_sorted ? 1u : 0u;
         for (uint32_t l = 0; l < MAX_LEVELS; ++l) {
-            const bool active = l >= a.level_lo && l < a.level_hi && l < a.levels;
+            const bool active = l >= level_lo && l < a.level_hi && l < a.levels;
             const bool skip = !active || already_sorted || (a.allow_skip && s_trivial[l]);
             a.plan->skip[l] = s_skip[l] = skip ? 1u : 0u;
             a.plan->src_is_tmp[l] = in_tmp;
@@ -1192,6 +1412,224 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_sort_kernel(K* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// K4: the hybrid route's last step.  After the two K3 passes the slice is ordered by the top 16
+// bits of the mapped key; bucket b = [bstart[b], bstart[b+1]) holds the keys with prefix b and is
+// at most one tile long.  One workgroup per bucket: the keys are read once (wave-striped, like a K3
+// tile), LSD-sorted by the remaining LEVELS-2 digits through LDS — per level K3's counting, tile
+// scan and ranking (returning LDS add + order test, ballots as fallback, group leaders for heavy
+// digits) — and written back in place with coalesced stores.  This is the device twin of what rdst
+// itself does below its two MSD levels at this size: Sorter::lsb_sort_adapter on ~15 k-key chunks
+// (src/sorts/lsb_sort.rs:39-127, picked by src/tuners/standard_tuner.rs:46-48).
+// Slots past the bucket's end hold the bucket's largest possible key (prefix | ones): a real key
+// that ties with it on every remaining digit has the same bits, so whichever of them lands in the
+// first `cnt` slots, the stored values are the same.
+// ------------------------------------------------------------------------------------------
+constexpr int local_waves(size_t key_bytes) { return key_bytes <= 4 ? 12 : 16; }
+constexpr int local_kpt(size_t key_bytes) { return key_bytes <= 4 ? 22 : 16; }
+constexpr int local_tile(size_t key_bytes) { return local_waves(key_bytes) * 64 * local_kpt(key_bytes); }
+constexpr size_t local_lds_bytes(size_t key_bytes) { return (size_t)local_waves(key_bytes) * 1024 + 64 + key_bytes * local_tile(key_bytes); }
+
+template <typename K, int NWAVES, int KPT, bool MAPPED>
+__global__ __launch_bounds__(NWAVES * 64, (sizeof(K) <= 4 ? 2 : 1) * NWAVES / 4) void local_sort_kernel(
+    K* __restrict__ buf_keys, K* __restrict__ buf_tmp, const uint32_t* __restrict__ bstart, const Plan* __restrict__ plan,
+    uint32_t* __restrict__ err, K neg, K pos, uint32_t flags) {
+    constexpr int BLOCK = NWAVES * 64, TILE = BLOCK * KPT, W = sizeof(K) * 8, LOCAL = (int)sizeof(K) - 2;
+    constexpr uint32_t SLOT_UNIT = (uint32_t)sizeof(K);  // running slots count in bytes of the staging buffer
+    static_assert(BLOCK >= RADIX && TILE <= 65536, "one thread per digit / 16-bit run indices");
+    if (!plan->local_sort) return;
+    K* __restrict__ buf = plan->result_in_tmp ? buf_tmp : buf_keys;
+    const uint32_t bucket = blockIdx.x;
+    const uint32_t start = bstart[bucket], cnt = bstart[bucket + 1] - start;
+    if (cnt <= 1) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (cnt > (uint32_t)TILE) {  // the route test rules it out; never sort a truncated bucket
+        if (tid == 0) atomicOr(err, ERR_LOCAL_OVERFLOW);
+        return;
+    }
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* wave_hist = reinterpret_cast<uint32_t*>(smem);                       // [NWAVES][256]
+    uint32_t* s_misc = reinterpret_cast<uint32_t*>(smem + NWAVES * 1024);          // [16]
+    unsigned char* stage = smem + NWAVES * 1024 + 64;                              // K[TILE]
+    // only as many rounds as the bucket needs: key index = wave * 64 * rounds + round * 64 + lane
+    const int rounds = (int)((cnt + BLOCK - 1) / BLOCK);
+    const uint32_t live = (uint32_t)rounds * BLOCK;
+    const uint32_t wbase = (uint32_t)wave * 64u * (uint32_t)rounds + (uint32_t)lane;
+    const K sentinel = (K)((K)bucket << (W - 16)) | (K)(((K)1 << (W - 16)) - 1);
+
+    __builtin_amdgcn_s_setprio(RDST_PRIO_LOAD);
+    K mk[KPT];
+    {
+        const K* tsrc = buf + start;
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            K v = sentinel;
+            if (i < rounds) {  // block-uniform
+                const uint32_t idx = wbase + i * 64;
+                const K raw = tsrc[idx < cnt ? idx : cnt - 1];
+                if (idx < cnt) v = MAPPED ? map_key<K>(raw, neg, pos) : raw;
+            }
+            mk[i] = v;
+        }
+    }
+    uint32_t* wh = wave_hist + wave * RADIX;
+#pragma unroll 1
+    for (int level = 0; level < LOCAL; ++level) {
+        const int shift = level * 8, bit0 = shift & 31;
+        __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wh[lane + 64 * j] = 0;
+        if (tid == 0) s_misc[0] = 0;  // "one digit holds every slot" flag of this level
+        // counting, as in K3 step 2
+        uint32_t uniform_rounds = 0;
+        uint32_t run_index[(KPT + 1) / 2];
+        bool careful, fast;
+        {
+            const uint32_t d0 = digit_of(mk[0], shift);
+            const uint32_t dn = (uint32_t)__builtin_amdgcn_mov_dpp((int)d0, 0x138, 0xf, 0xf, false);
+            careful = __builtin_popcountll(__builtin_amdgcn_ballot_w64(d0 == dn) & ~1ull) >= 8;
+            fast = !careful && (flags & RDST_FAST_RANK);
+            if (careful) {
+#pragma unroll
+                for (int i = 0; i < KPT; ++i) {
+                    if (i < rounds) {
+                        const uint32_t d = digit_of(mk[i], shift);
+                        if (__all((int)(d == (uint32_t)__builtin_amdgcn_readfirstlane((int)d))) != 0) {
+                            if (lane == 0) wh[d] += 64u;
+                            uniform_rounds |= 1u << i;
+                        } else {
+                            uint32_t total;
+                            const uint32_t below = peers_below_total(digit_word<K>(mk[i], shift), bit0, total);
+                            if (below == 0) atomicAdd(&wh[d], total);
+                        }
+                    }
+                }
+            } else if (fast) {
+#pragma unroll
+                for (int i = 0; i < KPT; ++i) {
+                    if (i < rounds) {
+                        const uint32_t r = atomicAdd(&wh[digit_of(mk[i], shift)], 1u);
+                        if (i & 1) run_index[i >> 1] |= r << 16;
+                        else run_index[i >> 1] = r;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < KPT; ++i)
+                    if (i < rounds) atomicAdd(&wh[digit_of(mk[i], shift)], 1u);
+            }
+        }
+        __syncthreads();
+        if (tid < RADIX) __builtin_amdgcn_s_setprio(RDST_PRIO_SCAN);
+        uint32_t cw[NWAVES];
+        uint32_t count_d = 0;
+        if (tid < RADIX) {
+#pragma unroll
+            for (int w = 0; w < NWAVES; ++w) {
+                cw[w] = wave_hist[w * RADIX + tid];
+                count_d += cw[w];
+            }
+            if (count_d == live) s_misc[0] = 1;  // nothing to reorder on this digit (block-wide)
+        }
+        uint32_t incl = count_d;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(incl, o);
+            if (lane >= o) incl += y;
+        }
+        if (tid < RADIX && lane == 63) s_misc[4 + wave] = incl;
+        __syncthreads();
+        if (s_misc[0]) {  // block-uniform
+            __syncthreads();  // every thread has read the flag before thread 0 clears it again
+            continue;
+        }
+        if (tid < RADIX) {
+            uint32_t woff = 0;
+            for (int w = 0; w < wave; ++w) woff += s_misc[4 + w];
+            uint32_t run = woff + incl - count_d;
+#pragma unroll
+            for (int w = 0; w < NWAVES; ++w) {
+                wave_hist[w * RADIX + tid] = run * SLOT_UNIT;  // first slot of (wave w, digit d)
+                run += cw[w];
+            }
+        }
+        __syncthreads();
+        __builtin_amdgcn_s_setprio(0);
+        // ranking, as in K3 step 5; the key goes straight to its slot of the staging buffer
+        bool ranked = false;
+        if (fast) {
+            bool out_of_order = false;
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                if (i < rounds) {
+                    const uint32_t idx = (i & 1) ? (run_index[i >> 1] >> 16) : (run_index[i >> 1] & 0xFFFFu);
+                    const uint32_t sl = wh[digit_of(mk[i], shift)] + idx * SLOT_UNIT;
+                    *reinterpret_cast<K*>(stage + sl) = mk[i];
+                    if (shift) {  // level 0 has no lower digits: any order will do
+                        const K prev = *reinterpret_cast<const K*>(stage + sl - SLOT_UNIT);
+                        const int up = W - shift;
+                        out_of_order |= idx != 0 && (K)(prev << up) > (K)(mk[i] << up);
+                    }
+                }
+            }
+            ranked = __builtin_amdgcn_ballot_w64(out_of_order) == 0 && !(flags & RDST_FAST_RANK_SELFTEST);
+        }
+        if (!ranked) {
+            if (!careful) {
+#pragma unroll
+                for (int i = 0; i < KPT; ++i) {
+                    if (i < rounds) {
+                        uint32_t* slot = &wh[digit_of(mk[i], shift)];
+                        const uint32_t b = *slot;
+                        const uint32_t below = peers_below(digit_word<K>(mk[i], shift), bit0);
+                        __builtin_amdgcn_wave_barrier();
+                        atomicAdd(slot, SLOT_UNIT);
+                        *reinterpret_cast<K*>(stage + b + below * SLOT_UNIT) = mk[i];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < KPT; ++i) {
+                    if (i < rounds) {
+                        uint32_t* slot = &wh[digit_of(mk[i], shift)];
+                        const uint32_t b = *slot;
+                        uint32_t below;
+                        if ((uniform_rounds >> i) & 1u) {
+                            below = (uint32_t)lane;
+                            __builtin_amdgcn_wave_barrier();
+                            if (lane == 0) *slot = b + 64u * SLOT_UNIT;
+                        } else {
+                            uint32_t total;
+                            below = peers_below_total(digit_word<K>(mk[i], shift), bit0, total);
+                            __builtin_amdgcn_wave_barrier();
+                            if (below == 0) *slot = b + total * SLOT_UNIT;
+                        }
+                        *reinterpret_cast<K*>(stage + b + below * SLOT_UNIT) = mk[i];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // the next level reads the slice back in its new order (wave-striped again)
+#pragma unroll
+        for (int i = 0; i < KPT; ++i)
+            if (i < rounds) mk[i] = reinterpret_cast<const K*>(stage)[wbase + i * 64];
+    }
+    // `mk` holds the sorted bucket in (wave, round, lane) order; out through LDS for coalesced stores would
+    // cost another round trip, and the wave-striped order already stores 256 contiguous bytes per instruction
+    __builtin_amdgcn_s_setprio(RDST_PRIO_SCATTER);
+    {
+        K* tdst = buf + start;
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            if (i < rounds) {
+                const uint32_t idx = wbase + i * 64;
+                if (idx < cnt) tdst[idx] = MAPPED ? unmap_key<K>(mk[i], neg, pos) : mk[i];
+            }
+        }
+    }
+}
+
 // result sits in tmp after an odd number of executed passes: copy back
 // (src/sorts/lsb_sort.rs:117-126)
 template <typename K, int VEC>
@@ -1253,6 +1691,8 @@ __global__ __launch_bounds__(256) void gather_records_kernel(const UNIT* __restr
         out[g] = rec[(uint64_t)idx[i] * units + w];
     }
 }
+
+__global__ void raise_error_kernel(uint32_t* err, uint32_t bits) { atomicOr(err, bits); }  // rdst_hip_debug_raise_device_error
 
 // K6: one level's histogram + "digit sequence has an inversion" flag
 template <typename K>
@@ -1320,7 +1760,16 @@ constexpr int default_cfg(uint32_t elem_bytes, uint64_t n) {
 // keys per thread for a key width, from the table's 8-byte figure: same bytes per thread
 constexpr int kpt_for(int kpt8, size_t elem_bytes) { return elem_bytes <= 4 ? kpt8 * 2 : (elem_bytes == 8 ? kpt8 : (kpt8 / 2) & ~1); }
 
-struct Tuning { int pass_cfg = -1; int hist_bpc = 0; bool profiling = false; bool chains = true; int fast_rank = 1; bool small_sort = true; };  // pass_cfg < 0: default_cfg()
+struct Tuning {
+    int pass_cfg = -1;  // < 0: default_cfg()
+    int hist_bpc = 0;
+    bool profiling = false;
+    bool chains = true;
+    int fast_rank = 1;
+    bool small_sort = true;
+    bool hybrid = true;                 // consider the hybrid route at all
+    uint64_t hybrid_min_len = 1ull << 28;  // below this the buckets are too small for one workgroup each to pay off
+};
 uint32_t g_ablate = 0;  // only ever set by the RDST_EXPERIMENTS build
 #ifdef RDST_EXPERIMENTS
 size_t g_exp_lds_total = 0;
@@ -1334,6 +1783,10 @@ struct DeviceState {
     void* ws = nullptr;
     size_t ws_bytes = 0;
     uint32_t* host_err = nullptr;  // pinned
+    // Device error word: a small allocation of its own, outside the per-sort workspace, so that it survives
+    // the clear at the start of every pipeline and a re-allocation of the workspace.  Kernels only OR
+    // into it; rdst_hip_device_status (and the blocking entry points) read AND clear it.
+    uint32_t* err_dev = nullptr;
     hipStream_t host_stream = nullptr;  // the host entry points' own stream: created once (creating and destroying one per call cost ~0.1 ms)
     void* host_buf = nullptr;           // their device buffer (keys + tmp), kept and grown on demand
     size_t host_buf_bytes = 0;
@@ -1341,9 +1794,12 @@ struct DeviceState {
     hipEvent_t last_done = nullptr;  // recorded after every enqueue that uses the workspace
     hipStream_t last_stream = nullptr;
     bool have_last = false;
+    bool last_plan_valid = false;  // the most recent call ran a pipeline whose Plan sits at last_plan_off of the workspace
+    size_t last_plan_off = 0;
     // per-kernel timing (rdst_hip_set_profiling): events recorded between the launches of the
     // most recent pipeline, on the stream the kernels run on
     std::vector<hipEvent_t> prof_events;
+    std::vector<uint32_t> prof_kinds;  // prof_kinds[i]: what ran between event i and event i + 1 (RDST_STAGE_* | level << 8)
     uint32_t prof_used = 0;
     struct ProfRun { uint32_t begin, count; };
     std::vector<ProfRun> prof_runs;  // one per pipeline since profiling was (re-)enabled
@@ -1353,8 +1809,8 @@ DeviceState g_dev[16];
 struct Layout {
     uint32_t levels, tile, status_bytes;  // status_bytes: 4 or 8 per word
     uint64_t tiles;
-    size_t off_err, off_tickets, off_plan, off_hpos, off_hpair, off_status, off_status_near, zero_bytes, off_hist, off_base, off_cbase,
-        off_chains, total;
+    size_t off_err, off_tickets, off_plan, off_hpos, off_hpair, off_h16, off_hpos16, off_status, off_status_near, zero_bytes, off_hist, off_base,
+        off_cbase, off_chains, off_bstart, total;
 };
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -1371,12 +1827,14 @@ Layout make_layout(uint64_t n, uint32_t elem_bytes, uint32_t levels, int cfg, ui
     L.tiles = n / L.tile + CHAINS + 2;  // status rows per level: every chain may end and begin on partial tiles
     L.status_bytes = n < (1ull << 30) ? 4 : 8;  // an inclusive prefix can reach n
     size_t o = 0;
-    L.off_err = o; o += 64;  // error word + (experiments build) look-back statistics
+    L.off_err = o; o += 64;  // cleared flags of one sort: [1] inversion seen, [2] a K1h counter overflowed (the error word itself lives in DeviceState::err_dev)
     o = align_up(o, 128);
     L.off_tickets = o; o += sizeof(uint32_t) * MAX_LEVELS * TICKET_ROW;  // per chain + mask of chains handed out, a line each
     L.off_plan = o; o += align_up(sizeof(Plan), 16);
     L.off_hpos = o; o += sizeof(uint64_t) * (size_t)levels * CHAINS * RADIX;
     L.off_hpair = o; o += sizeof(uint64_t) * (size_t)levels * CHAINS * RADIX;
+    L.off_h16 = o; o += sizeof(uint32_t) * (size_t)H16_BINS;              // hybrid route: bucket counts (K1h)
+    L.off_hpos16 = o; o += sizeof(uint64_t) * (size_t)CHAINS * RADIX;     // and its level L-2 counts per position range
     L.off_status = o; o += (size_t)L.status_bytes * levels * L.tiles * RADIX;
     L.off_status_near = o; o += (size_t)L.status_bytes * levels * L.tiles * RADIX;
     L.zero_bytes = align_up(o, 16); o = L.zero_bytes;  // everything up to here is cleared per sort
@@ -1384,6 +1842,8 @@ Layout make_layout(uint64_t n, uint32_t elem_bytes, uint32_t levels, int cfg, ui
     L.off_base = o; o += sizeof(uint64_t) * (size_t)levels * RADIX;
     L.off_cbase = o; o += sizeof(uint64_t) * (size_t)levels * CHAINS * RADIX;
     L.off_chains = o; o += sizeof(LevelChains) * (size_t)levels;
+    o = align_up(o, 16);
+    L.off_bstart = o; o += sizeof(uint32_t) * ((size_t)H16_BINS + 4);     // hybrid route: bucket starts
     L.total = align_up(o, 256);
     return L;
 }
@@ -1404,6 +1864,8 @@ int current_device_state(DeviceState** out, int* dev_out = nullptr) {
         }
         D.cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         HIP_TRY(hipHostMalloc((void**)&D.host_err, 64, hipHostMallocDefault));
+        HIP_TRY(hipMalloc((void**)&D.err_dev, 256));
+        HIP_TRY(hipMemset(D.err_dev, 0, 256));
         HIP_TRY(hipEventCreateWithFlags(&D.last_done, hipEventDisableTiming));
         D.init = true;
     }
@@ -1439,15 +1901,30 @@ int workspace_release(DeviceState& D, hipStream_t s) {
     return RDST_OK;
 }
 
-int prof_mark(DeviceState& D, hipStream_t s) {
+// `kind`: the stage that ENDS at this mark (ignored for a run's first mark)
+int prof_mark(DeviceState& D, hipStream_t s, uint32_t kind = 0) {
     if (!g_tuning.profiling || D.prof_runs.empty() || D.prof_used >= 8192) return RDST_OK;
     if (D.prof_used == D.prof_events.size()) {
         hipEvent_t e;
         HIP_TRY(hipEventCreate(&e));
         D.prof_events.push_back(e);
+        D.prof_kinds.push_back(0);
     }
+    if (D.prof_used > D.prof_runs.back().begin) D.prof_kinds[D.prof_used - 1] = kind;
     HIP_TRY(hipEventRecord(D.prof_events[D.prof_used++], s));
     D.prof_runs.back().count = D.prof_used - D.prof_runs.back().begin;
+    return RDST_OK;
+}
+
+// hipFuncSetAttribute acts on the CURRENT device's copy of the function: remember (device, kernel) -> bytes
+int ensure_lds_attr(const void* fn, size_t lds) {
+    static std::map<std::pair<int, const void*>, size_t> done;  // callers hold g_mutex
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    auto it = done.find({dev, fn});
+    if (it != done.end() && it->second == lds) return RDST_OK;
+    HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    done[{dev, fn}] = lds;
     return RDST_OK;
 }
 
@@ -1463,17 +1940,12 @@ KeyMap key_map_for(rdst_key_kind kind, uint32_t elem_bytes) {
 
 template <typename K, int LEVELS, int VEC, bool PAIR>
 int launch_hist_v(const K* keys, uint64_t n, uint32_t blocks, KeyMap km, unsigned long long* hpos, unsigned long long* hpair,
-                  uint32_t* inversion, hipStream_t s, uint64_t* piece_out) {
+                  uint32_t* inversion, const Plan* plan, hipStream_t s, uint64_t* piece_out) {
     *piece_out = hist_piece(n, blocks, (uint64_t)HIST_THREADS * VEC * 4);
     constexpr size_t lds = (size_t)HistPlan<LEVELS, PAIR>::WORDS * sizeof(uint32_t);
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&hist_kernel<K, LEVELS, VEC, PAIR>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&hist_kernel<K, LEVELS, VEC, PAIR>), lds)) return rc;
     hipLaunchKernelGGL((hist_kernel<K, LEVELS, VEC, PAIR>), dim3(blocks), dim3(HIST_THREADS), lds, s, keys, n, (K)km.neg,
-                       (K)km.pos, hpos, hpair, inversion);
+                       (K)km.pos, hpos, hpair, inversion, plan);
     HIP_TRY(hipGetLastError());
     return RDST_OK;
 }
@@ -1481,17 +1953,56 @@ int launch_hist_v(const K* keys, uint64_t n, uint32_t blocks, KeyMap km, unsigne
 // pair == true also fills the joint tables the chain split of the later passes needs
 template <typename K, int LEVELS>
 int launch_hist(const K* keys, uint64_t n, uint32_t blocks, KeyMap km, unsigned long long* hpos, unsigned long long* hpair,
-                bool pair, uint32_t* inversion, hipStream_t s, uint64_t* piece_out) {
+                bool pair, uint32_t* inversion, const Plan* plan, hipStream_t s, uint64_t* piece_out) {
     const bool aligned = (reinterpret_cast<uintptr_t>(keys) & 15u) == 0;
     constexpr int V = 16 / sizeof(K);
     if constexpr (LEVELS >= 2) {
         if (pair) {
-            if (aligned) return launch_hist_v<K, LEVELS, V, true>(keys, n, blocks, km, hpos, hpair, inversion, s, piece_out);
-            return launch_hist_v<K, LEVELS, 1, true>(keys, n, blocks, km, hpos, hpair, inversion, s, piece_out);
+            if (aligned) return launch_hist_v<K, LEVELS, V, true>(keys, n, blocks, km, hpos, hpair, inversion, plan, s, piece_out);
+            return launch_hist_v<K, LEVELS, 1, true>(keys, n, blocks, km, hpos, hpair, inversion, plan, s, piece_out);
         }
     }
-    if (aligned) return launch_hist_v<K, LEVELS, V, false>(keys, n, blocks, km, hpos, hpair, inversion, s, piece_out);
-    return launch_hist_v<K, LEVELS, 1, false>(keys, n, blocks, km, hpos, hpair, inversion, s, piece_out);
+    if (aligned) return launch_hist_v<K, LEVELS, V, false>(keys, n, blocks, km, hpos, hpair, inversion, plan, s, piece_out);
+    return launch_hist_v<K, LEVELS, 1, false>(keys, n, blocks, km, hpos, hpair, inversion, plan, s, piece_out);
+}
+
+// K1h: the hybrid route's 65 536-bin count (same grid and pieces as K1)
+template <typename K>
+int launch_hist16(const K* keys, uint64_t n, uint32_t blocks, KeyMap km, uint32_t* h16, unsigned long long* hpos16, uint32_t* inversion,
+                  uint32_t* overflow, hipStream_t s) {
+    const bool aligned = (reinterpret_cast<uintptr_t>(keys) & 15u) == 0;
+    const bool mapped = km.neg != 0 || km.pos != 0;
+    constexpr int V = 16 / sizeof(K);
+    constexpr size_t lds = (size_t)H16_WORDS * sizeof(uint32_t);
+#define RDST_H16(VEC, MAPPED)                                                                                              \
+    do {                                                                                                                   \
+        if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&hist16_kernel<K, VEC, MAPPED>), lds)) return rc;       \
+        hipLaunchKernelGGL((hist16_kernel<K, VEC, MAPPED>), dim3(blocks), dim3(HIST_THREADS), lds, s, keys, n, (K)km.neg,  \
+                           (K)km.pos, h16, hpos16, inversion, overflow);                                                   \
+    } while (0)
+    if (aligned) { if (mapped) RDST_H16(V, true); else RDST_H16(V, false); }
+    else { if (mapped) RDST_H16(1, true); else RDST_H16(1, false); }
+#undef RDST_H16
+    HIP_TRY(hipGetLastError());
+    return RDST_OK;
+}
+
+// K4: one workgroup per bucket of the hybrid route
+template <typename K>
+int launch_local_sort(K* keys, K* tmp, const uint32_t* bstart, const Plan* plan, uint32_t* err, KeyMap km, hipStream_t s) {
+    constexpr int NW = local_waves(sizeof(K)), KPT = local_kpt(sizeof(K));
+    constexpr size_t lds = local_lds_bytes(sizeof(K));
+    const bool mapped = km.neg != 0 || km.pos != 0;
+    const uint32_t flags = (g_tuning.fast_rank ? RDST_FAST_RANK : 0u) | (g_tuning.fast_rank == 2 ? RDST_FAST_RANK_SELFTEST : 0u);
+    if (mapped) {
+        if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_sort_kernel<K, NW, KPT, true>), lds)) return rc;
+        hipLaunchKernelGGL((local_sort_kernel<K, NW, KPT, true>), dim3(H16_BINS), dim3(NW * 64), lds, s, keys, tmp, bstart, plan, err, (K)km.neg, (K)km.pos, flags);
+    } else {
+        if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_sort_kernel<K, NW, KPT, false>), lds)) return rc;
+        hipLaunchKernelGGL((local_sort_kernel<K, NW, KPT, false>), dim3(H16_BINS), dim3(NW * 64), lds, s, keys, tmp, bstart, plan, err, (K)km.neg, (K)km.pos, flags);
+    }
+    HIP_TRY(hipGetLastError());
+    return RDST_OK;
 }
 
 template <typename K, typename S, int KPT, int NWAVES, int STAGES, bool MAPPED, bool NARROW, typename V = NoVal>
@@ -1500,21 +2011,19 @@ int launch_pass_t(K* keys, K* tmp, uint64_t n, int level, const Layout& L, char*
     constexpr int TILE = NWAVES * 64 * KPT;
     size_t lds = (size_t)pass_lds_bytes(NWAVES, NARROW ? 4 : 8, ((int)sizeof(K) + ValBytes<V>::value) * (TILE / STAGES));
     auto kernel = &onesweep_kernel<K, S, KPT, NWAVES, STAGES, MAPPED, NARROW, V>;
-    static size_t attr_lds = 0;
 #ifdef RDST_EXPERIMENTS
     if (g_exp_lds_total > lds) lds = g_exp_lds_total;  // fewer blocks per CU
 #endif
-    if (attr_lds != lds) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_lds = lds;
-    }
+    if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(kernel), lds)) return rc;
     const uint64_t* cbase = reinterpret_cast<const uint64_t*>(ws + L.off_cbase) + (size_t)level * CHAINS * RADIX;
     S* status = reinterpret_cast<S*>(ws + L.off_status) + (size_t)level * L.tiles * RADIX;
     S* status_near = reinterpret_cast<S*>(ws + L.off_status_near) + (size_t)level * L.tiles * RADIX;
     const LevelChains* chains = reinterpret_cast<const LevelChains*>(ws + L.off_chains) + level;
     uint32_t* ticket = reinterpret_cast<uint32_t*>(ws + L.off_tickets) + (size_t)level * TICKET_ROW;
     const Plan* plan = reinterpret_cast<const Plan*>(ws + L.off_plan);
-    uint32_t* err = reinterpret_cast<uint32_t*>(ws + L.off_err);
+    DeviceState* D = nullptr;
+    if (int rc = current_device_state(&D)) return rc;
+    uint32_t* err = D->err_dev;
     (void)cus;
     const dim3 grid((uint32_t)L.tiles), block(NWAVES * 64);  // >= one block per tile of any chain split
     hipLaunchKernelGGL((onesweep_kernel<K, S, KPT, NWAVES, STAGES, MAPPED, NARROW, V>), grid, block, lds, s, keys, tmp, vals, vtmp, n,
@@ -1593,16 +2102,13 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
             const KeyMap km = key_map_for(kind, sizeof(K));
             const size_t lds = (size_t)SMALL_WAVES * 1024 + 16 + sizeof(K) * SMALL_THREADS * small_kpt(sizeof(K));
             const bool mapped = km.neg != 0 || km.pos != 0;
-            static bool attr_set[2] = {false, false};
-            if (!attr_set[mapped]) {
-                const void* fn = mapped ? reinterpret_cast<const void*>(&small_sort_kernel<K, LEVELS, true>)
-                                        : reinterpret_cast<const void*>(&small_sort_kernel<K, LEVELS, false>);
-                HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                attr_set[mapped] = true;
-            }
+            const void* fn = mapped ? reinterpret_cast<const void*>(&small_sort_kernel<K, LEVELS, true>)
+                                    : reinterpret_cast<const void*>(&small_sort_kernel<K, LEVELS, false>);
+            if ((rc = ensure_lds_attr(fn, lds))) return rc;
             if (mapped) hipLaunchKernelGGL((small_sort_kernel<K, LEVELS, true>), dim3(1), dim3(SMALL_THREADS), lds, s, keys, (uint32_t)n, (K)km.neg, (K)km.pos);
             else hipLaunchKernelGGL((small_sort_kernel<K, LEVELS, false>), dim3(1), dim3(SMALL_THREADS), lds, s, keys, (uint32_t)n, (K)km.neg, (K)km.pos);
             HIP_TRY(hipGetLastError());
+            D->last_plan_valid = false;
             return RDST_OK;
         }
     }
@@ -1631,7 +2137,7 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
             HIP_TRY(hipMemsetAsync(ws + status_lo + (L.off_status_near - L.off_status), 0, status_hi - status_lo, s));
         }
     }
-    if ((rc = prof_mark(*D, s))) return rc;
+    if ((rc = prof_mark(*D, s, RDST_STAGE_CLEAR))) return rc;
 
     // K1: one 128-KiB-LDS block per CU (more only on request), but no more than the data needs
     uint64_t blocks = (uint64_t)(g_tuning.hist_bpc > 0 ? g_tuning.hist_bpc : 1) * D->cus;
@@ -1651,9 +2157,40 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     // the joint tables pay off only when a second pass can follow a first
     const bool pair = g_tuning.chains && LEVELS >= 2 && level_hi > level_lo + 1;
     unsigned long long* hpair = reinterpret_cast<unsigned long long*>(ws + L.off_hpair);
-    rc = launch_hist<K, LEVELS>(keys, n, (uint32_t)blocks, km, hpos, hpair, pair, inversion, s, &piece);
+    Plan* plan = reinterpret_cast<Plan*>(ws + L.off_plan);
+    // Hybrid route (whole sorts of 4- and 8-byte keys, long enough that a bucket is worth a workgroup, short
+    // enough that 65 536 tiles can hold it): K1h counts the buckets, route_kernel decides.  If it says LSD,
+    // K1 below runs as ever (the slice is then read twice for counting); if it says hybrid, K1 returns at once.
+    bool try_hybrid = false;
+    if constexpr (!HAS_V && (sizeof(K) == 4 || sizeof(K) == 8)) {
+        try_hybrid = g_tuning.hybrid && level_lo == 0 && level_hi == (uint32_t)LEVELS && allow_skip && copy_back &&
+                     n >= g_tuning.hybrid_min_len && n <= (uint64_t)H16_BINS * local_tile(sizeof(K)) && n < (1ull << 32);
+        if (try_hybrid) {
+            uint32_t* overflow = reinterpret_cast<uint32_t*>(ws + L.off_err) + 2;
+            uint32_t* h16 = reinterpret_cast<uint32_t*>(ws + L.off_h16);
+            unsigned long long* hpos16 = reinterpret_cast<unsigned long long*>(ws + L.off_hpos16);
+            rc = launch_hist16<K>(keys, n, (uint32_t)blocks, km, h16, hpos16, inversion, overflow, s);
+            if (rc) return rc;
+            if ((rc = prof_mark(*D, s, RDST_STAGE_HIST16))) return rc;
+            RouteArgs ra{};
+            ra.h16 = h16;
+            ra.hpos16 = hpos16;
+            ra.overflow = overflow;
+            ra.bstart = reinterpret_cast<uint32_t*>(ws + L.off_bstart);
+            ra.hpos = hpos;
+            ra.hpair = hpair;
+            ra.plan = plan;
+            ra.n = n;
+            ra.levels = (uint32_t)LEVELS;
+            ra.cap = (uint32_t)local_tile(sizeof(K));
+            hipLaunchKernelGGL(route_kernel, dim3(1), dim3(1024), 0, s, ra);
+            HIP_TRY(hipGetLastError());
+            if ((rc = prof_mark(*D, s, RDST_STAGE_ROUTE))) return rc;
+        }
+    }
+    rc = launch_hist<K, LEVELS>(keys, n, (uint32_t)blocks, km, hpos, hpair, pair, inversion, try_hybrid ? plan : nullptr, s, &piece);
     if (rc) return rc;
-    if ((rc = prof_mark(*D, s))) return rc;
+    if ((rc = prof_mark(*D, s, RDST_STAGE_HIST))) return rc;
     ScanArgs sa{};
     sa.hpos = hpos;
     sa.hpair = pair ? hpair : nullptr;
@@ -1661,7 +2198,7 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     sa.base = reinterpret_cast<uint64_t*>(ws + L.off_base);
     sa.cbase = reinterpret_cast<uint64_t*>(ws + L.off_cbase);
     sa.chains = reinterpret_cast<LevelChains*>(ws + L.off_chains);
-    sa.plan = reinterpret_cast<Plan*>(ws + L.off_plan);
+    sa.plan = plan;
     sa.tickets = reinterpret_cast<uint32_t*>(ws + L.off_tickets);
     sa.inversion = inversion;
     sa.n = n;
@@ -1675,12 +2212,19 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     sa.use_chains = g_tuning.chains ? 1u : 0u;
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(256 * SCAN_GROUPS), 0, s, sa);
     HIP_TRY(hipGetLastError());
-    if ((rc = prof_mark(*D, s))) return rc;
+    if ((rc = prof_mark(*D, s, RDST_STAGE_SCAN))) return rc;
     for (uint32_t level = level_lo; level < level_hi; ++level) {
         if constexpr (HAS_V) rc = launch_pass_pairs<K, V>(keys, tmp, vals, vtmp, n, (int)level, L, ws, km, D->cus, s);
         else rc = launch_pass<K>(cfg, keys, tmp, n, (int)level, L, ws, km, D->cus, s);
         if (rc) return rc;
-        if ((rc = prof_mark(*D, s))) return rc;
+        if ((rc = prof_mark(*D, s, RDST_STAGE_PASS | (level << 8)))) return rc;
+    }
+    if constexpr (!HAS_V && (sizeof(K) == 4 || sizeof(K) == 8)) {
+        if (try_hybrid) {
+            rc = launch_local_sort<K>(keys, tmp, reinterpret_cast<const uint32_t*>(ws + L.off_bstart), plan, D->err_dev, km, s);
+            if (rc) return rc;
+            if ((rc = prof_mark(*D, s, RDST_STAGE_LOCAL))) return rc;
+        }
     }
     if (copy_back) {
         const bool aligned = ((reinterpret_cast<uintptr_t>(keys) | reinterpret_cast<uintptr_t>(tmp)) & 15u) == 0;
@@ -1707,10 +2251,12 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
                 hipLaunchKernelGGL((copyback_kernel<V, 1>), dim3((uint32_t)vblocks), dim3(256), 0, s, vals, vtmp, n, plan);
             HIP_TRY(hipGetLastError());
         }
-        if ((rc = prof_mark(*D, s))) return rc;
+        if ((rc = prof_mark(*D, s, RDST_STAGE_COPYBACK))) return rc;
     }
     if (layout_out) *layout_out = L;
     if (ws_out) *ws_out = ws;
+    D->last_plan_valid = true;
+    D->last_plan_off = L.off_plan;
     return workspace_release(*D, s);
 }
 
@@ -1739,12 +2285,15 @@ int check_common(const void* p, uint64_t len, uint32_t elem_bytes, rdst_key_kind
 }
 
 int read_device_error(DeviceState& D, hipStream_t s) {
-    if (!D.ws) return RDST_OK;
-    HIP_TRY(hipMemcpyAsync(D.host_err, D.ws, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if (!D.err_dev) return RDST_OK;
+    HIP_TRY(hipMemcpyAsync(D.host_err, D.err_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (*D.host_err != 0) {
-        char b[128];
-        snprintf(b, sizeof b, "device error word = 0x%x (1 = look-back spin bound expired, 2 = scatter destination out of range)", *D.host_err);
+        const uint32_t word = *D.host_err;
+        HIP_TRY(hipMemsetAsync(D.err_dev, 0, sizeof(uint32_t), s));  // reported once: the next check starts clean
+        HIP_TRY(hipStreamSynchronize(s));
+        char b[192];
+        snprintf(b, sizeof b, "device error word = 0x%x (1 = look-back spin bound expired, 2 = scatter destination out of range, 4 = hybrid-route bucket larger than a tile)", word);
         return fail(RDST_ERR_DEVICE, b);
     }
     return RDST_OK;
@@ -1777,6 +2326,38 @@ int rdst_hip_set_fast_rank(int enabled) {
 int rdst_hip_set_small_sort(int enabled) {
     std::lock_guard<std::mutex> lock(g_mutex);
     g_tuning.small_sort = enabled != 0;
+    return RDST_OK;
+}
+
+int rdst_hip_set_hybrid(int enabled, uint64_t min_len) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    g_tuning.hybrid = enabled != 0;
+    g_tuning.hybrid_min_len = min_len ? min_len : (1ull << 28);
+    return RDST_OK;
+}
+
+int rdst_hip_last_route(void* stream, uint32_t* route_out) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    DeviceState* D;
+    int rc = current_device_state(&D);
+    if (rc) return rc;
+    if (!route_out) return fail(RDST_ERR_ARG, "null output");
+    *route_out = RDST_ROUTE_LSD;
+    if (!D->ws || !D->last_plan_valid) return RDST_OK;  // no pipeline yet (or the one-workgroup sort)
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemcpyAsync(D->host_err + 4, static_cast<char*>(D->ws) + D->last_plan_off + offsetof(Plan, route), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    *route_out = D->host_err[4];
+    return RDST_OK;
+}
+
+int rdst_hip_debug_raise_device_error(uint32_t bits, void* stream) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    DeviceState* D;
+    int rc = current_device_state(&D);
+    if (rc) return rc;
+    hipLaunchKernelGGL(raise_error_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), D->err_dev, bits);
+    HIP_TRY(hipGetLastError());
     return RDST_OK;
 }
 
@@ -1856,6 +2437,23 @@ int rdst_hip_profile_run(int run, float* out_ms, uint32_t capacity, uint32_t* n_
     const uint32_t n = r.count - 1;
     for (uint32_t i = 0; i < n && i < capacity; ++i)
         HIP_TRY(hipEventElapsedTime(&out_ms[i], D->prof_events[r.begin + i], D->prof_events[r.begin + i + 1]));
+    *n_out = n < capacity ? n : capacity;
+    return RDST_OK;
+}
+
+int rdst_hip_profile_run_stages(int run, uint32_t* stages_out, uint32_t capacity, uint32_t* n_out) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    DeviceState* D;
+    int rc = current_device_state(&D);
+    if (rc) return rc;
+    if (!stages_out || !n_out) return fail(RDST_ERR_ARG, "null output");
+    *n_out = 0;
+    if (run < 0) run += (int)D->prof_runs.size();
+    if (run < 0 || run >= (int)D->prof_runs.size()) return fail(RDST_ERR_ARG, "no such profiled run");
+    const auto r = D->prof_runs[run];
+    if (r.count < 2) return RDST_OK;
+    const uint32_t n = r.count - 1;
+    for (uint32_t i = 0; i < n && i < capacity; ++i) stages_out[i] = D->prof_kinds[r.begin + i];
     *n_out = n < capacity ? n : capacity;
     return RDST_OK;
 }

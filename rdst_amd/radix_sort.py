@@ -355,18 +355,51 @@ def profile_runs() -> int:
     return int(_lib.load().rdst_hip_profile_runs())
 
 
+STAGE_NAMES = {1: "clear", 2: "histogram", 3: "scan", 4: "pass", 5: "copy_back", 6: "histogram16", 7: "route", 8: "local_sort"}
+
+
 def profile_run(run: int, levels: int):
-    """Stage times (ms) of recorded run `run` (negative: from the most recent): dict with
-    'clear', 'histogram', 'scan', 'passes' (one per level) and 'copy_back'."""
+    """Stage times (ms) of recorded run `run` (negative: from the most recent): dict with 'clear',
+    'histogram', 'scan', 'passes' (one per level the call covered; a level the plan skipped shows its
+    early-exit time), 'copy_back', and on calls that tried the hybrid route 'histogram16', 'route',
+    'local_sort'; 'stages' lists (name, level or None, ms) in launch order."""
     lib = _lib.load()
-    buf = (ctypes.c_float * 32)()
-    n = ctypes.c_uint32(0)
-    _lib.check(lib.rdst_hip_profile_run(int(run), buf, 32, ctypes.byref(n)))
-    v = [float(buf[i]) for i in range(n.value)]
-    if len(v) < 3 + levels:
+    buf = (ctypes.c_float * 64)()
+    kinds = (ctypes.c_uint32 * 64)()
+    n, nk = ctypes.c_uint32(0), ctypes.c_uint32(0)
+    _lib.check(lib.rdst_hip_profile_run(int(run), buf, 64, ctypes.byref(n)))
+    _lib.check(lib.rdst_hip_profile_run_stages(int(run), kinds, 64, ctypes.byref(nk)))
+    if n.value == 0 or n.value != nk.value:
         return None
-    return {"clear": v[0], "histogram": v[1], "scan": v[2], "passes": v[3:3 + levels],
-            "copy_back": v[3 + levels] if len(v) > 3 + levels else 0.0}
+    out = {"clear": 0.0, "histogram": 0.0, "scan": 0.0, "passes": [], "copy_back": 0.0, "stages": []}
+    for i in range(n.value):
+        code, level = kinds[i] & 0xFF, (kinds[i] >> 8) & 0xFF
+        name = STAGE_NAMES.get(code, f"stage{code}")
+        ms = float(buf[i])
+        out["stages"].append((name, level if name == "pass" else None, ms))
+        if name == "pass":
+            out["passes"].append(ms)
+        else:
+            out[name] = out.get(name, 0.0) + ms
+    if len(out["passes"]) < levels:
+        return None
+    return out
+
+
+def set_hybrid(enabled=True, min_len=0):
+    """Route choice knob (rdst_hip_set_hybrid): consider the hybrid route for sorts of at least `min_len` keys
+    (0 = built-in threshold)."""
+    _lib.check(_lib.load().rdst_hip_set_hybrid(int(bool(enabled)), int(min_len)))
+
+
+def last_route(device=None) -> str:
+    """'lsd' or 'hybrid': the route the most recent sort on the current stream's device took."""
+    import torch
+    lib = _lib.load()
+    r = ctypes.c_uint32(0)
+    with torch.cuda.device(device):
+        _lib.check(lib.rdst_hip_last_route(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), ctypes.byref(r)))
+    return "hybrid" if r.value == 1 else "lsd"
 
 
 def last_profile(levels: int):

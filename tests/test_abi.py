@@ -25,7 +25,7 @@ def test_exports_every_declared_symbol(hiplib):
 
 
 def test_abi_version(hiplib):
-    assert hiplib.rdst_hip_abi_version() == 1
+    assert hiplib.rdst_hip_abi_version() == 2
 
 
 def test_argument_validation_happens_before_any_device_call(hiplib):

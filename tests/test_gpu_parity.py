@@ -24,7 +24,7 @@ def _device_sort(rdst, a):
 def test_native_library_is_the_one_in_tree(gpu):
     from rdst_amd import _lib
     assert os.path.dirname(_lib.LIB_PATH) == os.path.join(os.path.dirname(HERE), "rdst_amd")
-    assert _lib.load().rdst_hip_abi_version() == 1
+    assert _lib.load().rdst_hip_abi_version() == 2
     maps = open("/proc/self/maps").read()
     assert "librdst_hip.so" in maps
 
