@@ -2,26 +2,33 @@
 """Headline benchmark: device-resident radix sort of 1 B uniform-random u32 keys per GPU
 (BASELINE.json configs[1]), Gkeys/s, with the dominant kernel's HBM roofline and a CPU baseline.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype u32|u64|f32]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A step = one sort of the workload.  N == 1: `rdst_hip_sort_device` on 10^9 keys already in HBM.
 N > 1 (weak scaling): every rank holds 10^9 keys; one step = the sharded route (local top-digit
-histogram, all-gather of the 256 counts, top-digit scatter, all-to-all over RCCL/xGMI, local LSD
-sort) — value = N * 10^9 * K keys / wall time.  Every step sorts a fresh unsorted copy
-that was placed in HBM before the timed region (no copies inside it).
+histogram, all-gather of the 256 counts, top-digit scatter, all-to-all over RCCL/xGMI, local
+sort) — value = N * 10^9 * K keys / wall time.  Every step sorts a fresh unsorted copy that was
+placed in HBM before the timed region (no copies inside it).
 
-The JSON line also carries:
-  roofline      the K3 scatter-pass kernel: algorithmic bytes per launch (8 B/key for u32: one
-                read + one write of every key) / its average launch duration, taken
-                with HIP events recorded between launches on the kernels' stream, inside the
-                timed region.
-  cpu_baseline  the oracle (C restatement of rdst's StandardTuner route, OpenMP) timed on this
-                box's host cores on a bounded sample of the same workload, rank 0, N == 1 only.
+The JSON line also carries (protocol of SURVEY.md §8(d) / BASELINE.md §3-4):
+  median_ms_per_step  median of the K steps (HIP events around each step, same stream) beside the mean
+  roofline       the dominant kernel (K3, one scatter pass): algorithmic bytes per launch (2k per key: one
+                 read + one write) / its average launch duration over the launches that moved keys, taken
+                 with HIP events recorded between launches on the kernels' stream, inside the timed region
+  kernels        the same for every stage of the route taken (K1h / K1, K3, K4 ...)
+  copy_ceiling   a measured device copy of the same array (read + write), beside the 8 TB/s spec
+  configs        N == 1: BASELINE configs[2] and [3] (10^9 u64, 10^9 f32) run after the timed region, same
+                 protocol, with their own roofline figures (B = 136 and 36 bytes per key)
+  end_to_end     `rdst_hip_sort` on a host slice of the same workload (PCIe both ways) — never `value`
+  cpu_baseline   the oracle (C restatement of rdst's StandardTuner route, OpenMP) timed on this box's host
+                 cores on THE SAME ARRAY the GPU leg sorted; the two outputs are compared bit for bit
 """
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -29,10 +36,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 KEYS_PER_GPU = 1_000_000_000
-SEED = 0x5D570002
 HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
-ELEM = 4
-LEVELS = 4
+# name -> (torch view dtype, numpy dtype, key bytes, levels, seed (C2, C3, C4))
+DTYPES = {
+    "u32": ("uint32", "uint32", 4, 4, 0x5D570002),
+    "u64": ("uint64", "uint64", 8, 8, 0x5D570003),
+    "f32": ("float32", "float32", 4, 4, 0x5D570004),
+}
 
 
 def effective_cpus():
@@ -47,33 +57,124 @@ def effective_cpus():
     return max(1, n)
 
 
-def cpu_baseline(n_total):
-    """Oracle (kind "port") on a bounded sample: ~10-20 s of CPU work."""
+def cargo_probe():
+    """the real rdst needs cargo; record that it is absent (expected)."""
+    try:
+        out = subprocess.run(["cargo", "--version"], capture_output=True, text=True, timeout=10)
+        return out.stdout.strip() or "cargo present but silent"
+    except Exception as e:  # noqa: BLE001
+        return f"absent ({type(e).__name__})"
+
+
+def cpu_baseline(host_keys, gpu_sorted_host):
+    """Oracle (kind "port") on the array the GPU leg sorted: median of 3 runs on fresh copies, and the
+    result compared bit for bit with the device's."""
     import numpy as np
     from oracle import oracle as O
     O.load()
     threads = effective_cpus()
-    rng = np.random.default_rng(SEED)
-
-    def run(n):
-        a = rng.integers(0, 1 << 32, size=n, dtype=np.uint32)
+    n = host_keys.size
+    times = []
+    out = None
+    for _ in range(3):
+        a = host_keys.copy()
         t0 = time.perf_counter()
         O.sort(a, tuner="standard", multi_threaded=True, threads=threads)
-        dt = time.perf_counter() - t0
-        assert bool((a[1:] >= a[:-1]).all())
-        return dt
-
-    probe = 50_000_000
-    t_probe = run(probe)
-    rate = probe / t_probe
-    n = int(min(n_total, max(probe, rate * 4.0)))      # ~4 s per run, 3 runs
-    n = max(60_000_000, n)                              # stay above the 50 M Scanning threshold of the 1 B route
-    n = min(n, n_total)
-    times = sorted(run(n) for _ in range(3))
-    med = times[1]
+        times.append(time.perf_counter() - t0)
+        out = a
+        if sum(times) > 45:   # slow host: one run is the sample
+            break
+    med = statistics.median(times)
+    w = host_keys.dtype.itemsize
+    equal = bool(np.array_equal(out.view(f"u{w}"), gpu_sorted_host.view(f"u{w}")))
+    assert equal, "CPU oracle and device outputs differ"
     return {"value": round(n / med / 1e9, 4), "unit": "Gkeys/s", "cores": threads, "kind": "port",
-            "sample": f"{n} uniform u32 keys (of the {n_total}-key workload), median of 3, "
-                      f"oracle/rdst_oracle.c StandardTuner route, {threads} OpenMP threads"}
+            "sample": f"the full {n}-key array the GPU leg sorted (D2H once, outside every clock), median of {len(times)}, "
+                      f"oracle/rdst_oracle.c StandardTuner route, {threads} OpenMP threads",
+            "bit_identical_to_device_output": equal, "cargo": cargo_probe()}
+
+
+def gen_keys(torch, n, name, seed):
+    """uniform random bit patterns of the key type, generated on the device"""
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    if DTYPES[name][2] == 4:
+        return torch.randint(-(2**31), 2**31, (n,), dtype=torch.int32, device="cuda", generator=g)
+    return torch.randint(-(2**63), 2**63 - 1, (n,), dtype=torch.int64, device="cuda", generator=g)
+
+
+def mapped_signed(torch, x, name):
+    """signed-comparable image of rdst's key order (src/radix_key_impl.rs) of the raw bits in x"""
+    mn = torch.iinfo(x.dtype).min
+    if name.startswith("u"):
+        return x ^ mn
+    if name.startswith("f"):
+        return torch.where(x < 0, ~x ^ mn, x)
+    return x
+
+
+def is_sorted(torch, m, chunk=1 << 27):
+    for s in range(0, m.numel(), chunk):
+        e = min(m.numel(), s + chunk + 1)
+        if not bool((m[s + 1:e] >= m[s:e - 1]).all()):
+            return False
+    return True
+
+
+def kernel_table(rdst_amd, runs, n, kb, levels):
+    """per-stage averages over the recorded pipelines: {stage: {avg_ms, launches, GBps, frac}}"""
+    acc = {}
+    for r in runs:
+        prof = rdst_amd.profile_run(r, levels)
+        if not prof:
+            continue
+        top = max(prof["passes"]) if prof["passes"] else 0.0
+        for name, _level, ms in prof["stages"]:
+            if name == "pass" and ms < 0.25 * top:
+                name = "pass_skipped"          # a level the plan turned off: the launch returns at once
+            if name == "histogram" and prof.get("local_sort", 0.0) > 0.25 * top and ms < 0.1:
+                name = "histogram_skipped"     # K1 returns at once on the hybrid route
+            acc.setdefault(name, []).append(ms)
+    alg = {"pass": 2 * kb * n, "local_sort": 2 * kb * n, "histogram": kb * n, "histogram16": kb * n}
+    out = {}
+    for name, v in acc.items():
+        avg = sum(v) / len(v)
+        e = {"avg_ms": round(avg, 4), "launches": len(v)}
+        if name in alg and avg > 0:
+            gbps = alg[name] / (avg * 1e-3) / 1e9
+            e.update({"algorithmic_bytes_per_launch": alg[name], "GBps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 4)})
+        out[name] = e
+    return out
+
+
+def timed_sorts(torch, rdst_amd, src, name, K, W, step=None, fence=None):
+    """W warm-up + K timed sorts of fresh copies of `src` (already in HBM).  Returns (elapsed s, per-step ms,
+    profiled run indices, last output)."""
+    view_dt = getattr(torch, DTYPES[name][0])
+    bufs = [src.clone().view(view_dt) for _ in range(K + W)]
+    tmp = torch.empty_like(bufs[0])
+    if step is None:
+        def step(buf):  # noqa: E306
+            rdst_amd.sort_device_tensor(buf, tmp, check=False)
+            return buf
+    if fence is None:
+        fence = torch.cuda.synchronize
+    out = None
+    for i in range(W):
+        out = step(bufs[i])
+    fence()
+    rdst_amd.set_profiling(True)   # HIP events between the launches of every timed step
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]
+    t0 = time.perf_counter()
+    ev[0].record()
+    for i in range(K):
+        out = step(bufs[W + i])
+        ev[i + 1].record()
+    fence()
+    elapsed = time.perf_counter() - t0
+    rdst_amd.device_status()       # any kernel failure of any step (the error word is sticky) raises here
+    runs = list(range(rdst_amd.profile_runs()))
+    per_step = [ev[i].elapsed_time(ev[i + 1]) for i in range(K)]
+    return elapsed, per_step, runs, out, bufs, tmp
 
 
 def main():
@@ -82,7 +183,10 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--keys", type=int, default=KEYS_PER_GPU, help="keys per GPU (default: the BASELINE workload)")
+    ap.add_argument("--dtype", choices=sorted(DTYPES), default="u32", help="key type of the timed region (default: the headline u32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the u64 / f32 configs, the copy ceiling and the end-to-end leg")
+    ap.add_argument("--route", choices=("auto", "lsd"), default="auto", help="lsd: never take the hybrid route (A/B)")
     args = ap.parse_args()
 
     import torch
@@ -109,48 +213,28 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    import numpy as np
     import rdst_amd
     from rdst_amd.sharded import sharded_sort
 
+    if args.route == "lsd":
+        rdst_amd.set_hybrid(False)
     n = args.keys
     K, W = args.steps, args.warmup
-    g = torch.Generator(device="cuda").manual_seed(SEED + rank)
-    src = torch.randint(-(2**31), 2**31, (n,), dtype=torch.int32, device="cuda", generator=g)
-    # one unsorted copy per step, resident before the clock starts
-    bufs = [src.clone().view(torch.uint32) for _ in range(K + W)]
-    tmp = torch.empty(n, dtype=torch.uint32, device="cuda")
-
-    def step(buf):
-        if distributed:
-            return sharded_sort(buf)
-        rdst_amd.sort_device_tensor(buf, tmp, check=False)
-        return buf
+    name = args.dtype
+    _vdt, npdt, kb, levels, seed = DTYPES[name]
+    B_key = kb * (2 * levels + 1)   # algorithmic bytes per key of the whole sort
 
     def fence():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
-    out = None
-    for i in range(W):
-        out = step(bufs[i])
-    fence()
-    rdst_amd.set_profiling(True)   # HIP events between the launches of every timed step
-    t0 = time.perf_counter()
-    for i in range(K):
-        out = step(bufs[W + i])
-    fence()
-    elapsed = time.perf_counter() - t0
-    rdst_amd.device_status()
-
-    # per-kernel durations over the timed region: every full-sort pipeline recorded above
-    pass_ms, hist_ms, clear_ms = [], [], []
-    for r in range(rdst_amd.profile_runs()):
-        prof = rdst_amd.profile_run(r, LEVELS)
-        if prof and len(prof["passes"]) == LEVELS and min(prof["passes"]) > 0:
-            pass_ms += prof["passes"]
-            hist_ms.append(prof["histogram"])
-            clear_ms.append(prof["clear"])
+    src = gen_keys(torch, n, name, seed + rank)
+    step = (lambda buf: sharded_sort(buf)) if distributed else None
+    elapsed, per_step, runs, out, bufs, tmp = timed_sorts(torch, rdst_amd, src, name, K, W, step=step, fence=fence)
+    route = rdst_amd.last_route()
+    kernels = kernel_table(rdst_amd, runs, n if not distributed else out.numel(), kb, levels)
     rdst_amd.set_profiling(False)
 
     if distributed:
@@ -158,50 +242,119 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # sanity of the last result (outside the clock)
-    chk = out.view(torch.int32) ^ (-(2**31))
-    assert bool((chk[1:] >= chk[:-1]).all()), "output not sorted"
+    # sanity of the last result (outside the clock): sorted, and (single GPU) the same multiset as its input
+    itype = torch.int32 if kb == 4 else torch.int64
+    assert is_sorted(torch, mapped_signed(torch, out.view(itype), name)), "output not sorted"
+    if not distributed:
+        assert int(out.view(itype).sum()) == int(src.sum()), "checksum differs: not a permutation of the input"
 
     total_keys = n * world * K
     value = total_keys / elapsed / 1e9
     ms_per_step = elapsed / K * 1e3
-    avg_pass = sum(pass_ms) / len(pass_ms) if pass_ms else None
-    bytes_per_launch = 2 * ELEM * (n if not distributed else out.numel())
     roof = None
-    if avg_pass:
-        ach = bytes_per_launch / (avg_pass * 1e-3) / 1e9
-        traffic = None
+    if "pass" in kernels:
+        kp = kernels["pass"]
+        traffic, traffic_src = None, None
         tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tp) and not distributed and n == KEYS_PER_GPU:
+        if os.path.exists(tp) and not distributed and n == KEYS_PER_GPU and name == "u32":
             try:
                 traffic = json.load(open(tp)).get("onesweep_pass_hbm_bytes_per_launch")
+                traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; not measured in this run)"
             except Exception:  # noqa: BLE001
                 traffic = None
-        roof = {"bound": "hbm", "kernel": "onesweep_kernel (K3, one scatter pass)", "achieved": round(ach, 1),
-                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": round(avg_pass, 4),
-                "launches_timed": len(pass_ms), "histogram_ms": round(sum(hist_ms) / len(hist_ms), 4),
-                "clear_ms": round(sum(clear_ms) / len(clear_ms), 4)}
+        roof = {"bound": "hbm", "kernel": "onesweep_kernel (K3, one scatter pass)", "achieved": kp["GBps"],
+                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": kp["frac"], "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": kp["algorithmic_bytes_per_launch"], "avg_launch_ms": kp["avg_ms"],
+                "launches_timed": kp["launches"]}
 
+    line = None
     if rank == 0:
         line = {
-            "metric": "radix_sort_throughput_1B_uniform_u32", "value": round(value, 3), "unit": "Gkeys/s",
+            "metric": f"radix_sort_throughput_1B_uniform_{name}", "value": round(value, 3), "unit": "Gkeys/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": f"{n} uniform-random u32 keys per GPU, device-resident, LSD 4 passes x 8 bits"
-                                   + (", sharded: MSD top byte + RCCL all-to-all + local LSD" if distributed else ""),
-                       "keys_per_gpu": n, "total_keys": n * world, "seed": SEED,
+            "median_ms_per_step": round(statistics.median(per_step), 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": name, "data": "synthetic",
+            "config": {"workload": f"{n} uniform-random {name} keys per GPU, device-resident; route '{route}': "
+                                   + ("K1h + 2 scatter passes on the top 16 bits + in-LDS sort of every bucket" if route == "hybrid"
+                                      else f"LSD, {levels} passes x 8 bits")
+                                   + (", sharded: MSD top byte + RCCL all-to-all + local sort" if distributed else ""),
+                       "keys_per_gpu": n, "total_keys": n * world, "seed": seed, "route": route,
                        "parallelism": f"shard{world}" if distributed else "single"},
-            "sort_algorithmic_GBps": round(total_keys * ELEM * (2 * LEVELS + 1) / elapsed / 1e9 / world, 1),
-            "sort_roofline_frac_per_gpu": round(total_keys * ELEM * (2 * LEVELS + 1) / elapsed / 1e9 / world / HBM_PEAK_GBPS, 4),
+            "sort_algorithmic_bytes_per_key": B_key,
+            "sort_algorithmic_GBps": round(total_keys * B_key / elapsed / 1e9 / world, 1),
+            "sort_roofline_frac_per_gpu": round(total_keys * B_key / elapsed / 1e9 / world / HBM_PEAK_GBPS, 4),
             "roofline": roof,
+            "kernels": kernels,
         }
-        if not distributed and not args.no_cpu_baseline:
-            del bufs, tmp, src
-            torch.cuda.empty_cache()
-            line["cpu_baseline"] = cpu_baseline(n)
-        else:
-            line["cpu_baseline"] = None
+
+    if rank == 0 and not distributed:
+        # ---- outside the timed region: copy ceiling, the other BASELINE configs, end to end, CPU leg
+        gpu_sorted_host = None
+        host_keys = None
+        if not args.no_cpu_baseline:
+            host_keys = src.cpu().numpy().view(npdt)          # D2H once, outside every clock
+            gpu_sorted_host = out.view(itype).cpu().numpy().view(npdt)
+        if not args.no_extras:
+            # measured device-copy ceiling on the same array: read + write of n*k bytes, 16 B per lane
+            a, b = bufs[0], tmp
+            for _ in range(2):
+                b.copy_(a)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                b.copy_(a)
+            e1.record()
+            torch.cuda.synchronize()
+            cms = e0.elapsed_time(e1) / 10
+            line["copy_ceiling"] = {"ms": round(cms, 4), "GBps": round(2 * kb * n / (cms * 1e-3) / 1e9, 1),
+                                    "frac_of_spec": round(2 * kb * n / (cms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                    "what": f"torch copy_ of the same {kb * n / 1e9:.1f} GB array (read + write), mean of 10"}
+        del bufs, tmp, out
+        torch.cuda.empty_cache()
+        if not args.no_extras:
+            configs = {}
+            for other in ("u64", "f32"):
+                if other == name or n != KEYS_PER_GPU:
+                    continue
+                _v2, _np2, kb2, lv2, seed2 = DTYPES[other]
+                src2 = gen_keys(torch, n, other, seed2)
+                k2 = max(3, min(K, 5))
+                el2, ps2, runs2, out2, bufs2, tmp2 = timed_sorts(torch, rdst_amd, src2, other, k2, 1)
+                it2 = torch.int32 if kb2 == 4 else torch.int64
+                assert is_sorted(torch, mapped_signed(torch, out2.view(it2), other)), f"{other}: output not sorted"
+                assert int(out2.view(it2).sum()) == int(src2.sum()), f"{other}: checksum differs"
+                B2 = kb2 * (2 * lv2 + 1)
+                med = statistics.median(ps2)
+                configs[other] = {"keys": n, "steps": k2, "route": rdst_amd.last_route(), "ms_per_step": round(el2 / k2 * 1e3, 4),
+                                  "median_ms_per_step": round(med, 4), "Gkeys_per_s": round(n * k2 / el2 / 1e9, 3),
+                                  "sort_algorithmic_bytes_per_key": B2,
+                                  "roofline": {"bound": "hbm", "achieved": round(n * k2 * B2 / el2 / 1e9, 1), "peak": HBM_PEAK_GBPS,
+                                               "unit": "GB/s", "frac": round(n * k2 * B2 / el2 / 1e9 / HBM_PEAK_GBPS, 4)},
+                                  "kernels": kernel_table(rdst_amd, runs2, n, kb2, lv2)}
+                rdst_amd.set_profiling(False)
+                del src2, out2, bufs2, tmp2
+                torch.cuda.empty_cache()
+            line["configs"] = configs
+            # end to end through the reference-shaped entry point: host slice in, host slice out (PCIe both ways)
+            if host_keys is None:
+                host_keys = src.cpu().numpy().view(npdt)
+            e2e = []
+            for _ in range(2):
+                h = host_keys.copy()
+                t0 = time.perf_counter()
+                rdst_amd.radix_sort_unstable(h)
+                e2e.append(time.perf_counter() - t0)
+            if gpu_sorted_host is not None:
+                assert np.array_equal(h.view(f"u{kb}"), gpu_sorted_host.view(f"u{kb}")), "host entry point and device path differ"
+            line["end_to_end"] = {"ms": round(min(e2e) * 1e3, 2), "Gkeys_per_s": round(n / min(e2e) / 1e9, 3),
+                                  "what": "rdst_hip_sort on a host numpy slice of the same keys: H2D + sort + D2H, best of 2 (never `value`)"}
+            del h
+        del src
+        torch.cuda.empty_cache()
+        line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(host_keys, gpu_sorted_host)
+    elif rank == 0:
+        line["cpu_baseline"] = None
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if distributed:
         dist.barrier()

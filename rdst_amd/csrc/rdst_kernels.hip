@@ -95,6 +95,7 @@ struct Plan {
     uint32_t chain_mode[MAX_LEVELS];  // how the pass's source splits into look-back chains (CHAIN_*)
     uint32_t result_in_tmp;           // where the data sits after the last executed pass
     uint32_t executed;                // number of passes executed
+    uint32_t first_level;             // lowest executed level: below it nothing has ordered the keys (order test of K3's fast ranking)
     uint32_t route;                   // ROUTE_LSD or ROUTE_HYBRID (decided on the device by route_kernel)
     uint32_t local_sort;              // hybrid route and the slice is not already sorted: K4 runs
 };
@@ -442,27 +443,52 @@ __global__ __launch_bounds__(HIST_THREADS) void hist16_kernel(const K* __restric
     struct alignas(sizeof(K) * VEC) V { K e[VEC]; };
     uint64_t i = p_begin + (uint64_t)tid * VEC;
     constexpr uint64_t STRIDE = (uint64_t)HIST_THREADS * VEC;
+    constexpr uint64_t S4 = 4 * STRIDE;  // one batch: four vectors per lane
     const uint64_t lane_rest = (uint64_t)(63 - (tid & 63)) * VEC;
-    for (; i + lane_rest + 3 * STRIDE + VEC <= p_end; i += 4 * STRIDE) {
-        V v[4];
+    // full batches of this wave (while its LAST lane still has one: whole waves enter and leave together)
+    const uint64_t need = i + lane_rest + 3 * STRIDE + VEC;
+    const uint64_t nb = need <= p_end ? (p_end - need) / S4 + 1 : 0;
+    // Loads run one batch ahead of the counting (two register sets, ping-pong): with one block per CU a
+    // wave that waits for its own loads before counting leaves the memory pipeline idle meanwhile.
+    auto load = [&](V (&v)[4], K (&edge)[4], uint64_t at) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const V*>(keys + i + u * STRIDE);
-        K edge[4];
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const V*>(keys + at + u * STRIDE);
+        // key before my vector = last key of the lane below; only lane 0 of a wave has to fetch it
 #pragma unroll
-        for (int u = 0; u < 4; ++u) edge[u] = ((tid & 63) == 0 && i + u * STRIDE > 0) ? keys[i + u * STRIDE - 1] : (K)0;
+        for (int u = 0; u < 4; ++u) edge[u] = ((tid & 63) == 0 && at + u * STRIDE > 0) ? keys[at + u * STRIDE - 1] : (K)0;
+    };
+    auto proc = [&](V (&v)[4], K (&edge)[4], uint64_t at) {
         const uint32_t b0 = (uint32_t)(mapped(v[0].e[0]) >> (W - 16));
         const bool careful = __all((int)(b0 == (uint32_t)__builtin_amdgcn_readfirstlane((int)b0))) != 0;
         auto batch = [&](bool c) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 K before = lane_below<K>(mapped(v[u].e[VEC - 1]));
-                if ((tid & 63) == 0) before = (i + u * STRIDE > 0) ? mapped(edge[u]) : (K)0;
+                if ((tid & 63) == 0) before = (at + u * STRIDE > 0) ? mapped(edge[u]) : (K)0;
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) before = count(v[u].e[e], before, c);
             }
         };
         if (careful) batch(true);
         else batch(false);
+    };
+    {
+        V va[4], vb[4];
+        K ea[4], eb[4];
+        uint64_t b = 0;
+        if (nb) load(va, ea, i);
+        while (b + 2 <= nb) {  // va holds batch b
+            load(vb, eb, i + S4);
+            proc(va, ea, i);
+            if (b + 2 < nb) load(va, ea, i + 2 * S4);
+            proc(vb, eb, i + S4);
+            i += 2 * S4;
+            b += 2;
+        }
+        if (b < nb) {
+            proc(va, ea, i);
+            i += S4;
+        }
     }
     for (; i < p_end; i += STRIDE) {
         K before = mapped_at(i);
@@ -657,7 +683,10 @@ __global__ __launch_bounds__(256 * SCAN_GROUPS) void scan_kernel(ScanArgs a) {
                 else if (prev == (int)l - 1 && a.hpair) mode = CHAIN_PAIR;
             }
             a.plan->chain_mode[l] = s_mode[l] = mode;
-            if (!skip) { in_tmp ^= 1u; ++executed; prev = (int)l; }
+            if (!skip) {
+                if (prev < 0) a.plan->first_level = l;
+                in_tmp ^= 1u; ++executed; prev = (int)l;
+            }
         }
         a.plan->result_in_tmp = in_tmp;
         a.plan->executed = executed;
@@ -1151,7 +1180,11 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8,
     // Pass 0 has no lower digits: any order will do.
     if constexpr (CAN_FAST) {
         if (fast) {
-            const int low_bits = shift;  // key bits below the current digit
+            // key bits the earlier passes of THIS sort have ordered: from the first executed level up to the
+            // current digit (the hybrid route starts at level L-2; the bits below stay unordered until K4)
+            const int lo = (int)plan->first_level * 8;
+            const int low_bits = shift > lo ? shift - lo : 0;
+            const K order_mask = low_bits ? (K)((((K)1 << low_bits) - 1) << lo) : (K)0;
             bool out_of_order = false;
 #pragma unroll
             for (int i = 0; i < KPT; ++i) {
@@ -1160,8 +1193,7 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8,
                 place(i, sl);
                 if (low_bits) {
                     const K prev = *reinterpret_cast<const K*>(reinterpret_cast<const unsigned char*>(s_keys) + sl - SLOT_UNIT);
-                    const int up = (int)sizeof(K) * 8 - low_bits;
-                    out_of_order |= idx != 0 && (K)(prev << up) > (K)(mk[i] << up);
+                    out_of_order |= idx != 0 && (K)(prev & order_mask) > (K)(mk[i] & order_mask);
                 }
             }
             // never seen to fail; the ballot loop below redoes the wave's tile share if it ever does
@@ -1431,16 +1463,11 @@ constexpr int local_tile(size_t key_bytes) { return local_waves(key_bytes) * 64 
 constexpr size_t local_lds_bytes(size_t key_bytes) { return (size_t)local_waves(key_bytes) * 1024 + 64 + key_bytes * local_tile(key_bytes); }
 
 template <typename K, int NWAVES, int KPT, bool MAPPED>
-__global__ __launch_bounds__(NWAVES * 64, (sizeof(K) <= 4 ? 2 : 1) * NWAVES / 4) void local_sort_kernel(
-    K* __restrict__ buf_keys, K* __restrict__ buf_tmp, const uint32_t* __restrict__ bstart, const Plan* __restrict__ plan,
-    uint32_t* __restrict__ err, K neg, K pos, uint32_t flags) {
+__device__ __forceinline__ void local_sort_bucket(K* __restrict__ buf, const uint32_t bucket, const uint32_t start, const uint32_t cnt,
+                                                  uint32_t* __restrict__ err, K neg, K pos, uint32_t flags) {
     constexpr int BLOCK = NWAVES * 64, TILE = BLOCK * KPT, W = sizeof(K) * 8, LOCAL = (int)sizeof(K) - 2;
     constexpr uint32_t SLOT_UNIT = (uint32_t)sizeof(K);  // running slots count in bytes of the staging buffer
     static_assert(BLOCK >= RADIX && TILE <= 65536, "one thread per digit / 16-bit run indices");
-    if (!plan->local_sort) return;
-    K* __restrict__ buf = plan->result_in_tmp ? buf_tmp : buf_keys;
-    const uint32_t bucket = blockIdx.x;
-    const uint32_t start = bstart[bucket], cnt = bstart[bucket + 1] - start;
     if (cnt <= 1) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (cnt > (uint32_t)TILE) {  // the route test rules it out; never sort a truncated bucket
@@ -1630,6 +1657,140 @@ __global__ __launch_bounds__(NWAVES * 64, (sizeof(K) <= 4 ? 2 : 1) * NWAVES / 4)
     }
 }
 
+// one workgroup per bucket (8-byte keys), or — `list` given — a few workgroups working off the list of
+// buckets the counting kernel below had to leave alone (4-byte keys)
+template <typename K, int NWAVES, int KPT, bool MAPPED>
+__global__ __launch_bounds__(NWAVES * 64, (sizeof(K) <= 4 ? 2 : 1) * NWAVES / 4) void local_sort_kernel(
+    K* __restrict__ buf_keys, K* __restrict__ buf_tmp, const uint32_t* __restrict__ bstart, const Plan* __restrict__ plan,
+    uint32_t* __restrict__ err, K neg, K pos, uint32_t flags, const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count) {
+    if (!plan->local_sort) return;
+    K* __restrict__ buf = plan->result_in_tmp ? buf_tmp : buf_keys;
+    if (list == nullptr) {
+        const uint32_t bucket = blockIdx.x;
+        const uint32_t start = bstart[bucket];
+        local_sort_bucket<K, NWAVES, KPT, MAPPED>(buf, bucket, start, bstart[bucket + 1] - start, err, neg, pos, flags);
+        return;
+    }
+    const uint32_t todo = *list_count;
+#pragma unroll 1
+    for (uint32_t e = blockIdx.x; e < todo; e += gridDim.x) {
+        const uint32_t bucket = list[e];
+        const uint32_t start = bstart[bucket];
+        local_sort_bucket<K, NWAVES, KPT, MAPPED>(buf, bucket, start, bstart[bucket + 1] - start, err, neg, pos, flags);
+        __syncthreads();  // the next bucket reuses the LDS
+    }
+}
+
+// K4 for 4-byte keys: counting sort BY VALUE.  Inside a bucket the top 16 bits are the bucket index, so a key
+// is its low 16 bits: nothing has to be moved or ranked — count the values, scan the counts, write the
+// values out in order.  65 536 four-bit counters (32 KiB of LDS; thread t owns values [64t, 64t + 64) as eight
+// words laid out k * 1024 + t, so its reads are conflict-free); one LDS atomic per key instead of the ~10 LDS
+// operations of two ranked passes, which is what bounded the generic kernel.  A counter that
+// passes 15 carries into its neighbour (or out of the word): the decoded counters then sum to less than the
+// bucket's length, which the scan sees for free; such a bucket (a value repeated 16 times among <= 16 896
+// keys: skewed low bits) is left untouched and queued for the generic kernel above.
+constexpr int COUNT_THREADS = 1024;
+constexpr int COUNT_TILE = local_tile(4);  // the route's bucket bound for 4-byte keys
+constexpr size_t count_lds_bytes() { return 32768 + 2 * (size_t)COUNT_TILE + 128; }
+
+template <bool MAPPED>
+__global__ __launch_bounds__(COUNT_THREADS, 8) void local_count_sort_kernel(
+    uint32_t* __restrict__ buf_keys, uint32_t* __restrict__ buf_tmp, const uint32_t* __restrict__ bstart, const Plan* __restrict__ plan,
+    uint32_t* __restrict__ err, uint32_t neg, uint32_t pos, uint32_t* __restrict__ list, uint32_t* __restrict__ list_count) {
+    constexpr int BLOCK = COUNT_THREADS, MAXR = (COUNT_TILE + BLOCK - 1) / BLOCK;
+    if (!plan->local_sort) return;
+    uint32_t* __restrict__ buf = plan->result_in_tmp ? buf_tmp : buf_keys;
+    const uint32_t bucket = blockIdx.x;
+    const uint32_t start = bstart[bucket], cnt = bstart[bucket + 1] - start;
+    if (cnt <= 1) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (cnt > (uint32_t)COUNT_TILE) {
+        if (tid == 0) atomicOr(err, ERR_LOCAL_OVERFLOW);
+        return;
+    }
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* cnt4 = reinterpret_cast<uint32_t*>(smem);                    // [8][1024] words of eight 4-bit counters
+    uint16_t* out16 = reinterpret_cast<uint16_t*>(smem + 32768);           // [COUNT_TILE] sorted low halves
+    uint32_t* s_wsum = reinterpret_cast<uint32_t*>(smem + 32768 + 2 * COUNT_TILE);  // [16] + flag
+    __builtin_amdgcn_s_setprio(RDST_PRIO_LOAD);
+    const uint32_t* tsrc = buf + start;
+    uint32_t raw[MAXR];
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) {
+        const uint32_t idx = (uint32_t)tid + i * BLOCK;
+        raw[i] = tsrc[idx < cnt ? idx : cnt - 1];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) cnt4[k * BLOCK + tid] = 0;
+    __syncthreads();
+    __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) {
+        const uint32_t idx = (uint32_t)tid + i * BLOCK;
+        if (idx < cnt) {
+            const uint32_t m = MAPPED ? map_key<uint32_t>(raw[i], neg, pos) : raw[i];
+            // value v = low 16 bits: owner thread v >> 6, its word (v >> 3) & 7, nibble v & 7
+            const uint32_t word = ((m >> 3) & 7u) * BLOCK + ((m >> 6) & 1023u);
+            atomicAdd(&cnt4[word], 1u << ((m & 7u) * 4));
+        }
+    }
+    __syncthreads();
+    uint32_t w[8];
+    uint32_t mine = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        w[k] = cnt4[k * BLOCK + tid];
+        const uint32_t t = (w[k] & 0x0F0F0F0Fu) + ((w[k] >> 4) & 0x0F0F0F0Fu);
+        mine = __builtin_amdgcn_sad_u8(t, 0u, mine);  // + the four byte sums
+    }
+    uint32_t incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(incl, o);
+        if (lane >= o) incl += y;
+    }
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    uint32_t p = incl - mine, total = 0;
+#pragma unroll
+    for (int x = 0; x < BLOCK / 64; ++x) {
+        const uint32_t ws = s_wsum[x];
+        if (x < wave) p += ws;
+        total += ws;
+    }
+    if (total != cnt) {  // block-uniform: some counter overflowed; the bucket stays as it is, for the generic kernel
+        if (tid == 0) list[atomicAdd(list_count, 1u)] = bucket;
+        return;
+    }
+    // emit: thread t writes its values, in order, each as often as counted
+    const uint32_t vbase = (uint32_t)tid * 64u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uint32_t c = (w[k] >> (4 * j)) & 15u;
+            const uint32_t v = vbase + (uint32_t)(k * 8 + j);
+            while (c) {
+                out16[p] = (uint16_t)v;
+                ++p;
+                --c;
+            }
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_s_setprio(RDST_PRIO_SCATTER);
+    uint32_t* tdst = buf + start;
+    const uint32_t prefix = bucket << 16;
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) {
+        const uint32_t idx = (uint32_t)tid + i * BLOCK;
+        if (idx < cnt) {
+            const uint32_t m = prefix | (uint32_t)out16[idx];
+            tdst[idx] = MAPPED ? unmap_key<uint32_t>(m, neg, pos) : m;
+        }
+    }
+}
+
 // result sits in tmp after an odd number of executed passes: copy back
 // (src/sorts/lsb_sort.rs:117-126)
 template <typename K, int VEC>
@@ -1768,6 +1929,7 @@ struct Tuning {
     int fast_rank = 1;
     bool small_sort = true;
     bool hybrid = true;                 // consider the hybrid route at all
+    bool count_sort = true;             // 4-byte keys: K4 as a counting sort by value (false: the generic ranked passes)
     uint64_t hybrid_min_len = 1ull << 28;  // below this the buckets are too small for one workgroup each to pay off
 };
 uint32_t g_ablate = 0;  // only ever set by the RDST_EXPERIMENTS build
@@ -1810,7 +1972,7 @@ struct Layout {
     uint32_t levels, tile, status_bytes;  // status_bytes: 4 or 8 per word
     uint64_t tiles;
     size_t off_err, off_tickets, off_plan, off_hpos, off_hpair, off_h16, off_hpos16, off_status, off_status_near, zero_bytes, off_hist, off_base,
-        off_cbase, off_chains, off_bstart, total;
+        off_cbase, off_chains, off_bstart, off_fblist, total;
 };
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -1827,7 +1989,7 @@ Layout make_layout(uint64_t n, uint32_t elem_bytes, uint32_t levels, int cfg, ui
     L.tiles = n / L.tile + CHAINS + 2;  // status rows per level: every chain may end and begin on partial tiles
     L.status_bytes = n < (1ull << 30) ? 4 : 8;  // an inclusive prefix can reach n
     size_t o = 0;
-    L.off_err = o; o += 64;  // cleared flags of one sort: [1] inversion seen, [2] a K1h counter overflowed (the error word itself lives in DeviceState::err_dev)
+    L.off_err = o; o += 64;  // cleared flags of one sort: [1] inversion seen, [2] a K1h counter overflowed, [3] length of the local-sort fallback list (the error word itself lives in DeviceState::err_dev)
     o = align_up(o, 128);
     L.off_tickets = o; o += sizeof(uint32_t) * MAX_LEVELS * TICKET_ROW;  // per chain + mask of chains handed out, a line each
     L.off_plan = o; o += align_up(sizeof(Plan), 16);
@@ -1844,6 +2006,7 @@ Layout make_layout(uint64_t n, uint32_t elem_bytes, uint32_t levels, int cfg, ui
     L.off_chains = o; o += sizeof(LevelChains) * (size_t)levels;
     o = align_up(o, 16);
     L.off_bstart = o; o += sizeof(uint32_t) * ((size_t)H16_BINS + 4);     // hybrid route: bucket starts
+    L.off_fblist = o; o += sizeof(uint32_t) * (size_t)H16_BINS;           // buckets left to the generic local sort (count: header word 3)
     L.total = align_up(o, 256);
     return L;
 }
@@ -1987,19 +2150,37 @@ int launch_hist16(const K* keys, uint64_t n, uint32_t blocks, KeyMap km, uint32_
     return RDST_OK;
 }
 
-// K4: one workgroup per bucket of the hybrid route
+// K4: one workgroup per bucket of the hybrid route.  4-byte keys: the counting kernel, then the generic one
+// over the (normally empty) list of buckets it could not take; 8-byte keys: the generic one over all buckets.
 template <typename K>
-int launch_local_sort(K* keys, K* tmp, const uint32_t* bstart, const Plan* plan, uint32_t* err, KeyMap km, hipStream_t s) {
+int launch_local_sort(K* keys, K* tmp, const uint32_t* bstart, const Plan* plan, uint32_t* err, KeyMap km, uint32_t* list,
+                      uint32_t* list_count, int cus, hipStream_t s) {
     constexpr int NW = local_waves(sizeof(K)), KPT = local_kpt(sizeof(K));
     constexpr size_t lds = local_lds_bytes(sizeof(K));
     const bool mapped = km.neg != 0 || km.pos != 0;
     const uint32_t flags = (g_tuning.fast_rank ? RDST_FAST_RANK : 0u) | (g_tuning.fast_rank == 2 ? RDST_FAST_RANK_SELFTEST : 0u);
+    const bool counting = sizeof(K) == 4 && g_tuning.count_sort;
+    if constexpr (sizeof(K) == 4) {
+        if (counting) {
+            constexpr size_t clds = count_lds_bytes();
+            if (mapped) {
+                if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_count_sort_kernel<true>), clds)) return rc;
+                hipLaunchKernelGGL((local_count_sort_kernel<true>), dim3(H16_BINS), dim3(COUNT_THREADS), clds, s, keys, tmp, bstart, plan, err, (uint32_t)km.neg, (uint32_t)km.pos, list, list_count);
+            } else {
+                if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_count_sort_kernel<false>), clds)) return rc;
+                hipLaunchKernelGGL((local_count_sort_kernel<false>), dim3(H16_BINS), dim3(COUNT_THREADS), clds, s, keys, tmp, bstart, plan, err, (uint32_t)km.neg, (uint32_t)km.pos, list, list_count);
+            }
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    const dim3 grid(counting ? (uint32_t)(2 * cus) : (uint32_t)H16_BINS);
+    const uint32_t* wl = counting ? list : nullptr;
     if (mapped) {
         if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_sort_kernel<K, NW, KPT, true>), lds)) return rc;
-        hipLaunchKernelGGL((local_sort_kernel<K, NW, KPT, true>), dim3(H16_BINS), dim3(NW * 64), lds, s, keys, tmp, bstart, plan, err, (K)km.neg, (K)km.pos, flags);
+        hipLaunchKernelGGL((local_sort_kernel<K, NW, KPT, true>), grid, dim3(NW * 64), lds, s, keys, tmp, bstart, plan, err, (K)km.neg, (K)km.pos, flags, wl, list_count);
     } else {
         if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_sort_kernel<K, NW, KPT, false>), lds)) return rc;
-        hipLaunchKernelGGL((local_sort_kernel<K, NW, KPT, false>), dim3(H16_BINS), dim3(NW * 64), lds, s, keys, tmp, bstart, plan, err, (K)km.neg, (K)km.pos, flags);
+        hipLaunchKernelGGL((local_sort_kernel<K, NW, KPT, false>), grid, dim3(NW * 64), lds, s, keys, tmp, bstart, plan, err, (K)km.neg, (K)km.pos, flags, wl, list_count);
     }
     HIP_TRY(hipGetLastError());
     return RDST_OK;
@@ -2221,7 +2402,8 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     }
     if constexpr (!HAS_V && (sizeof(K) == 4 || sizeof(K) == 8)) {
         if (try_hybrid) {
-            rc = launch_local_sort<K>(keys, tmp, reinterpret_cast<const uint32_t*>(ws + L.off_bstart), plan, D->err_dev, km, s);
+            rc = launch_local_sort<K>(keys, tmp, reinterpret_cast<const uint32_t*>(ws + L.off_bstart), plan, D->err_dev, km,
+                                      reinterpret_cast<uint32_t*>(ws + L.off_fblist), reinterpret_cast<uint32_t*>(ws + L.off_err) + 3, D->cus, s);
             if (rc) return rc;
             if ((rc = prof_mark(*D, s, RDST_STAGE_LOCAL))) return rc;
         }
@@ -2332,6 +2514,7 @@ int rdst_hip_set_small_sort(int enabled) {
 int rdst_hip_set_hybrid(int enabled, uint64_t min_len) {
     std::lock_guard<std::mutex> lock(g_mutex);
     g_tuning.hybrid = enabled != 0;
+    g_tuning.count_sort = enabled != 2;  // 2: hybrid route with the generic local sort for every key width (A/B, tests)
     g_tuning.hybrid_min_len = min_len ? min_len : (1ull << 28);
     return RDST_OK;
 }

@@ -14,9 +14,11 @@ pytestmark = pytest.mark.gpu
 TILE = {4: 16896, 8: 16384}  # K4 tile = largest bucket the hybrid route accepts
 
 
-@pytest.fixture()
-def hybrid(gpu):
-    gpu.set_hybrid(True, min_len=1)   # consider the route at every length (default: 2^28 and up)
+@pytest.fixture(params=["count", "ranked"])
+def hybrid(gpu, request):
+    """both forms of K4 for 4-byte keys: the counting sort by value (default) and the generic ranked passes
+    (what 8-byte keys always use, and the fallback for buckets whose counters overflow)"""
+    gpu.set_hybrid(True if request.param == "count" else 2, min_len=1)   # consider the route at every length (default: 2^28 and up)
     yield gpu
     gpu.set_hybrid(True, 0)
     gpu.set_tuning()
