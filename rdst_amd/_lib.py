@@ -36,6 +36,8 @@ SYMBOLS = (
     "rdst_hip_set_hybrid",
     "rdst_hip_last_route",
     "rdst_hip_debug_raise_device_error",
+    "rdst_hip_stream_copy",
+    "rdst_hip_stream_read",
     "rdst_hip_last_error",
     "rdst_hip_abi_version",
 )
@@ -101,6 +103,8 @@ def load():
     lib.rdst_hip_set_hybrid.argtypes = [ci, u64]
     lib.rdst_hip_last_route.argtypes = [vp, ctypes.POINTER(u32)]
     lib.rdst_hip_debug_raise_device_error.argtypes = [u32, vp]
+    lib.rdst_hip_stream_copy.argtypes = [vp, vp, u64, vp]
+    lib.rdst_hip_stream_read.argtypes = [vp, u64, vp]
     lib.rdst_hip_last_error.restype = ctypes.c_char_p
     for name in SYMBOLS:
         if name not in ("rdst_hip_workspace_bytes", "rdst_hip_last_error"):

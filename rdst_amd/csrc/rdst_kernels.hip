@@ -1682,22 +1682,36 @@ __global__ __launch_bounds__(NWAVES * 64, (sizeof(K) <= 4 ? 2 : 1) * NWAVES / 4)
 }
 
 // K4 for 4-byte keys: counting sort BY VALUE.  Inside a bucket the top 16 bits are the bucket index, so a key
-// is its low 16 bits: nothing has to be moved or ranked — count the values, scan the counts, write the
-// values out in order.  65 536 four-bit counters (32 KiB of LDS; thread t owns values [64t, 64t + 64) as eight
-// words laid out k * 1024 + t, so its reads are conflict-free); one LDS atomic per key instead of the ~10 LDS
-// operations of two ranked passes, which is what bounded the generic kernel.  A counter that
-// passes 15 carries into its neighbour (or out of the word): the decoded counters then sum to less than the
-// bucket's length, which the scan sees for free; such a bucket (a value repeated 16 times among <= 16 896
-// keys: skewed low bits) is left untouched and queued for the generic kernel above.
-constexpr int COUNT_THREADS = 1024;
+// is its low 16 bits: nothing has to be ranked wave by wave or moved twice.
+//   count     one RETURNING LDS add per key on a table of 65 536 four-bit counters (32 KiB): the nibble it
+//             returns is the key's index among the keys of the same value (any order among equal keys is THE
+//             order: they are the same bits)
+//   scan      thread t owns values [VPT*t, VPT*t + VPT) as words k * BLOCK + t (conflict-free); it writes a
+//             16-bit exclusive prefix per word (8 values)
+//   place     every key: prefix of its word + the nibbles below its own in that word + its index -> its slot
+//   store     the sorted low halves go through LDS (the tables are dead by then and lend the space) and out
+//             with coalesced stores, prefix and inverse key map applied on the way
+// ~5 LDS operations and ~30 vector instructions per key, no divergence; the ranked two-pass form above costs
+// twice the LDS work, which is what bounds it.  A value seen 16 times in one bucket (skewed low
+// bits) would carry into the neighbouring counter: the add that would do it sees the nibble at 15, the block
+// then leaves the bucket untouched and queues it for the generic kernel above.
 constexpr int COUNT_TILE = local_tile(4);  // the route's bucket bound for 4-byte keys
-constexpr size_t count_lds_bytes() { return 32768 + 2 * (size_t)COUNT_TILE + 128; }
+constexpr size_t count_lds_bytes() { return 32768 + 16384 + 128; }
+static_assert(2 * (size_t)COUNT_TILE <= 32768 + 16384, "the output staging aliases the counter and prefix tables");
 
-template <bool MAPPED>
-__global__ __launch_bounds__(COUNT_THREADS, 8) void local_count_sort_kernel(
+__device__ __forceinline__ uint32_t nibble_sum(uint32_t x, uint32_t acc) {
+    const uint32_t t = (x & 0x0F0F0F0Fu) + ((x >> 4) & 0x0F0F0F0Fu);
+    return __builtin_amdgcn_sad_u8(t, 0u, acc);  // acc + the four byte sums
+}
+
+template <int BLOCK, bool MAPPED>
+__global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 8 : 6) void local_count_sort_kernel(
     uint32_t* __restrict__ buf_keys, uint32_t* __restrict__ buf_tmp, const uint32_t* __restrict__ bstart, const Plan* __restrict__ plan,
     uint32_t* __restrict__ err, uint32_t neg, uint32_t pos, uint32_t* __restrict__ list, uint32_t* __restrict__ list_count) {
-    constexpr int BLOCK = COUNT_THREADS, MAXR = (COUNT_TILE + BLOCK - 1) / BLOCK;
+    constexpr int MAXR = (COUNT_TILE + BLOCK - 1) / BLOCK;
+    constexpr int VPT = H16_BINS / BLOCK, WPT = VPT / 8;  // values / counter words per thread
+    constexpr int LOG_VPT = BLOCK == 1024 ? 6 : (BLOCK == 512 ? 7 : 8);
+    static_assert((1 << LOG_VPT) == VPT, "block size");
     if (!plan->local_sort) return;
     uint32_t* __restrict__ buf = plan->result_in_tmp ? buf_tmp : buf_keys;
     const uint32_t bucket = blockIdx.x;
@@ -1709,83 +1723,93 @@ __global__ __launch_bounds__(COUNT_THREADS, 8) void local_count_sort_kernel(
         return;
     }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t* cnt4 = reinterpret_cast<uint32_t*>(smem);                    // [8][1024] words of eight 4-bit counters
-    uint16_t* out16 = reinterpret_cast<uint16_t*>(smem + 32768);           // [COUNT_TILE] sorted low halves
-    uint32_t* s_wsum = reinterpret_cast<uint32_t*>(smem + 32768 + 2 * COUNT_TILE);  // [16] + flag
+    uint32_t* cnt4 = reinterpret_cast<uint32_t*>(smem);                    // [WPT][BLOCK] words of eight 4-bit counters
+    uint16_t* prefix = reinterpret_cast<uint16_t*>(smem + 32768);          // [WPT][BLOCK] keys below the word's first value
+    uint16_t* out16 = reinterpret_cast<uint16_t*>(smem);                   // [cnt] sorted low halves (aliases both, later)
+    uint32_t* s_wsum = reinterpret_cast<uint32_t*>(smem + 32768 + 16384);  // [16] wave sums, [16] overflow flag
     __builtin_amdgcn_s_setprio(RDST_PRIO_LOAD);
     const uint32_t* tsrc = buf + start;
-    uint32_t raw[MAXR];
+    uint32_t kv[MAXR];
 #pragma unroll
     for (int i = 0; i < MAXR; ++i) {
         const uint32_t idx = (uint32_t)tid + i * BLOCK;
-        raw[i] = tsrc[idx < cnt ? idx : cnt - 1];
+        kv[i] = tsrc[idx < cnt ? idx : cnt - 1];
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) cnt4[k * BLOCK + tid] = 0;
+    for (int k = 0; k < WPT; ++k) cnt4[k * BLOCK + tid] = 0;
+    if (tid == 0) s_wsum[16] = 0;
     __syncthreads();
     __builtin_amdgcn_s_setprio(0);
+    auto word_of = [](uint32_t v) -> uint32_t { return ((v >> 3) & (uint32_t)(WPT - 1)) * BLOCK + (v >> LOG_VPT); };
+    bool over = false;
 #pragma unroll
     for (int i = 0; i < MAXR; ++i) {
         const uint32_t idx = (uint32_t)tid + i * BLOCK;
         if (idx < cnt) {
-            const uint32_t m = MAPPED ? map_key<uint32_t>(raw[i], neg, pos) : raw[i];
-            // value v = low 16 bits: owner thread v >> 6, its word (v >> 3) & 7, nibble v & 7
-            const uint32_t word = ((m >> 3) & 7u) * BLOCK + ((m >> 6) & 1023u);
-            atomicAdd(&cnt4[word], 1u << ((m & 7u) * 4));
+            const uint32_t v = (MAPPED ? map_key<uint32_t>(kv[i], neg, pos) : kv[i]) & 0xFFFFu;
+            const uint32_t sh = (v & 7u) * 4u;
+            const uint32_t old = atomicAdd(&cnt4[word_of(v)], 1u << sh);
+            const uint32_t mine = (old >> sh) & 15u;
+            over |= mine == 15u;
+            kv[i] = v | (mine << 16);
         }
     }
+    if (over) s_wsum[16] = 1;
     __syncthreads();
-    uint32_t w[8];
-    uint32_t mine = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        w[k] = cnt4[k * BLOCK + tid];
-        const uint32_t t = (w[k] & 0x0F0F0F0Fu) + ((w[k] >> 4) & 0x0F0F0F0Fu);
-        mine = __builtin_amdgcn_sad_u8(t, 0u, mine);  // + the four byte sums
-    }
-    uint32_t incl = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t y = __shfl_up(incl, o);
-        if (lane >= o) incl += y;
-    }
-    if (lane == 63) s_wsum[wave] = incl;
-    __syncthreads();
-    uint32_t p = incl - mine, total = 0;
-#pragma unroll
-    for (int x = 0; x < BLOCK / 64; ++x) {
-        const uint32_t ws = s_wsum[x];
-        if (x < wave) p += ws;
-        total += ws;
-    }
-    if (total != cnt) {  // block-uniform: some counter overflowed; the bucket stays as it is, for the generic kernel
+    if (s_wsum[16]) {  // block-uniform: the bucket stays as it is, for the generic kernel
         if (tid == 0) list[atomicAdd(list_count, 1u)] = bucket;
         return;
     }
-    // emit: thread t writes its values, in order, each as often as counted
-    const uint32_t vbase = (uint32_t)tid * 64u;
+    {
+        uint32_t pre[WPT];
+        uint32_t run = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            uint32_t c = (w[k] >> (4 * j)) & 15u;
-            const uint32_t v = vbase + (uint32_t)(k * 8 + j);
-            while (c) {
-                out16[p] = (uint16_t)v;
-                ++p;
-                --c;
-            }
+        for (int k = 0; k < WPT; ++k) {
+            pre[k] = run;
+            run = nibble_sum(cnt4[k * BLOCK + tid], run);
         }
+        uint32_t incl = run;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(incl, o);
+            if (lane >= o) incl += y;
+        }
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        uint32_t base = incl - run;
+#pragma unroll
+        for (int x = 0; x < BLOCK / 64; ++x)
+            if (x < wave) base += s_wsum[x];
+#pragma unroll
+        for (int k = 0; k < WPT; ++k) prefix[k * BLOCK + tid] = (uint16_t)(base + pre[k]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) {
+        const uint32_t idx = (uint32_t)tid + i * BLOCK;
+        if (idx < cnt) {
+            const uint32_t v = kv[i] & 0xFFFFu, mine = kv[i] >> 16;
+            const uint32_t wd = word_of(v);
+            const uint32_t below = cnt4[wd] & ((1u << ((v & 7u) * 4u)) - 1u);
+            const uint32_t slot = nibble_sum(below, (uint32_t)prefix[wd] + mine);
+            kv[i] = v | (slot << 16);
+        }
+    }
+    __syncthreads();  // every read of the tables is done: their space becomes the output staging
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) {
+        const uint32_t idx = (uint32_t)tid + i * BLOCK;
+        if (idx < cnt) out16[kv[i] >> 16] = (uint16_t)kv[i];
     }
     __syncthreads();
     __builtin_amdgcn_s_setprio(RDST_PRIO_SCATTER);
     uint32_t* tdst = buf + start;
-    const uint32_t prefix = bucket << 16;
+    const uint32_t top = bucket << 16;
 #pragma unroll
     for (int i = 0; i < MAXR; ++i) {
         const uint32_t idx = (uint32_t)tid + i * BLOCK;
         if (idx < cnt) {
-            const uint32_t m = prefix | (uint32_t)out16[idx];
+            const uint32_t m = top | (uint32_t)out16[idx];
             tdst[idx] = MAPPED ? unmap_key<uint32_t>(m, neg, pos) : m;
         }
     }
@@ -1851,6 +1875,35 @@ __global__ __launch_bounds__(256) void gather_records_kernel(const UNIT* __restr
         const uint32_t w = (uint32_t)(g - i * units);
         out[g] = rec[(uint64_t)idx[i] * units + w];
     }
+}
+
+// Streaming yardsticks for the bench (rdst_hip_stream_copy / rdst_hip_stream_read): 16 bytes per lane, four
+// vectors in flight, grid-stride — what this HBM delivers to the simplest kernel there is, beside the 8 TB/s spec.
+__global__ __launch_bounds__(256) void stream_copy_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, uint64_t nvec) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < nvec; i += 4 * stride) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = src[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) dst[i + u * stride] = v[u];
+    }
+    for (; i < nvec; i += stride) dst[i] = src[i];
+}
+__global__ __launch_bounds__(256) void stream_read_kernel(const uint4* __restrict__ src, uint64_t nvec, uint32_t* __restrict__ sink) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t acc = 0;
+    for (; i + 3 * stride < nvec; i += 4 * stride) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = src[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+    }
+    for (; i < nvec; i += stride) acc ^= src[i].x ^ src[i].w;
+    if (acc == 0x9E3779B9u) *sink = acc;  // keeps the loads alive; practically never taken
 }
 
 __global__ void raise_error_kernel(uint32_t* err, uint32_t bits) { atomicOr(err, bits); }  // rdst_hip_debug_raise_device_error
@@ -2150,6 +2203,7 @@ int launch_hist16(const K* keys, uint64_t n, uint32_t blocks, KeyMap km, uint32_
     return RDST_OK;
 }
 
+constexpr int COUNT_THREADS = 1024;
 // K4: one workgroup per bucket of the hybrid route.  4-byte keys: the counting kernel, then the generic one
 // over the (normally empty) list of buckets it could not take; 8-byte keys: the generic one over all buckets.
 template <typename K>
@@ -2164,11 +2218,11 @@ int launch_local_sort(K* keys, K* tmp, const uint32_t* bstart, const Plan* plan,
         if (counting) {
             constexpr size_t clds = count_lds_bytes();
             if (mapped) {
-                if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_count_sort_kernel<true>), clds)) return rc;
-                hipLaunchKernelGGL((local_count_sort_kernel<true>), dim3(H16_BINS), dim3(COUNT_THREADS), clds, s, keys, tmp, bstart, plan, err, (uint32_t)km.neg, (uint32_t)km.pos, list, list_count);
+                if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_count_sort_kernel<COUNT_THREADS, true>), clds)) return rc;
+                hipLaunchKernelGGL((local_count_sort_kernel<COUNT_THREADS, true>), dim3(H16_BINS), dim3(COUNT_THREADS), clds, s, keys, tmp, bstart, plan, err, (uint32_t)km.neg, (uint32_t)km.pos, list, list_count);
             } else {
-                if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_count_sort_kernel<false>), clds)) return rc;
-                hipLaunchKernelGGL((local_count_sort_kernel<false>), dim3(H16_BINS), dim3(COUNT_THREADS), clds, s, keys, tmp, bstart, plan, err, (uint32_t)km.neg, (uint32_t)km.pos, list, list_count);
+                if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_count_sort_kernel<COUNT_THREADS, false>), clds)) return rc;
+                hipLaunchKernelGGL((local_count_sort_kernel<COUNT_THREADS, false>), dim3(H16_BINS), dim3(COUNT_THREADS), clds, s, keys, tmp, bstart, plan, err, (uint32_t)km.neg, (uint32_t)km.pos, list, list_count);
             }
             HIP_TRY(hipGetLastError());
         }
@@ -2531,6 +2585,32 @@ int rdst_hip_last_route(void* stream, uint32_t* route_out) {
     HIP_TRY(hipMemcpyAsync(D->host_err + 4, static_cast<char*>(D->ws) + D->last_plan_off + offsetof(Plan, route), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     *route_out = D->host_err[4];
+    return RDST_OK;
+}
+
+int rdst_hip_stream_copy(void* dev_dst, const void* dev_src, uint64_t bytes, void* stream) {
+    if (!dev_dst || !dev_src) return fail(RDST_ERR_ARG, "null pointer");
+    if ((reinterpret_cast<uintptr_t>(dev_dst) | reinterpret_cast<uintptr_t>(dev_src) | bytes) & 15u) return fail(RDST_ERR_ALIGN, "16-byte alignment");
+    std::lock_guard<std::mutex> lock(g_mutex);
+    DeviceState* D;
+    int rc = current_device_state(&D);
+    if (rc) return rc;
+    hipLaunchKernelGGL(stream_copy_kernel, dim3((uint32_t)D->cus * 8), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<uint4*>(dev_dst),
+                       static_cast<const uint4*>(dev_src), bytes / 16);
+    HIP_TRY(hipGetLastError());
+    return RDST_OK;
+}
+
+int rdst_hip_stream_read(const void* dev_src, uint64_t bytes, void* stream) {
+    if (!dev_src) return fail(RDST_ERR_ARG, "null pointer");
+    if ((reinterpret_cast<uintptr_t>(dev_src) | bytes) & 15u) return fail(RDST_ERR_ALIGN, "16-byte alignment");
+    std::lock_guard<std::mutex> lock(g_mutex);
+    DeviceState* D;
+    int rc = current_device_state(&D);
+    if (rc) return rc;
+    hipLaunchKernelGGL(stream_read_kernel, dim3((uint32_t)D->cus * 8), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const uint4*>(dev_src),
+                       bytes / 16, D->err_dev + 8);
+    HIP_TRY(hipGetLastError());
     return RDST_OK;
 }
 
