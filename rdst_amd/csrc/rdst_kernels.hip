@@ -1339,7 +1339,7 @@ ranked:
         }
     }
     // cannot happen with consistent counts; the range test keeps a logic error from faulting
-    if (bad) atomicOr(err, ERR_SCATTER_RANGE);
+    if (bad) atomicOr(err, ERR_SCATTER_RANGE | ((uint32_t)(level + 1) << 8));  // bits 8..: which level(s) (diagnostics)
 #ifdef RDST_EXPERIMENTS
     RDST_STAMP(9);
     if (tl_on) {
@@ -2862,16 +2862,38 @@ int rdst_hip_sort(void* host_data, uint64_t len, uint32_t elem_bytes, rdst_key_k
     if (!D->host_stream && (e = hipStreamCreateWithFlags(&D->host_stream, hipStreamNonBlocking)) != hipSuccess)
         return done(fail(RDST_ERR_HIP, "hipStreamCreate", e));
     hipStream_t s = D->host_stream;
-    if (D->host_buf_bytes < 2 * half) {
+    // RDST_HOST_ALLOC=pool re-creates the allocation scheme of commit 74cafa2 (one stream-ordered pool allocation
+    // per call) — kept only so that the abort that version once produced can be examined
+    static const char* alloc_mode = getenv("RDST_HOST_ALLOC");
+    static const bool use_pool = alloc_mode && strncmp(alloc_mode, "pool", 4) == 0;
+    static const bool pool_sync = alloc_mode && strcmp(alloc_mode, "pool_sync") == 0;    // + stream sync between H2D and the sort
+    static const bool host_debug = getenv("RDST_HOST_DEBUG") != nullptr;                // print the buffers of every call
+    static const bool pool_nofree = alloc_mode && strcmp(alloc_mode, "pool_nofree") == 0;  // blocks are never returned: no recycling
+    void* pool_buf = nullptr;
+    if (use_pool) {
+        if ((e = hipMallocAsync(&pool_buf, 2 * half, s)) != hipSuccess) return done(fail(RDST_ERR_HIP, "hipMallocAsync(keys + tmp)", e));
+    } else if (D->host_buf_bytes < 2 * half) {
         if (D->host_buf) { (void)hipStreamSynchronize(s); (void)hipFree(D->host_buf); D->host_buf = nullptr; D->host_buf_bytes = 0; }
         const size_t want = 2 * half < (size_t)(64u << 20) ? 2 * half + (2 * half) / 2 : 2 * half;  // head room for small slices only
         if ((e = hipMalloc(&D->host_buf, want)) != hipSuccess) return done(fail(RDST_ERR_HIP, "hipMalloc(keys + tmp)", e));
         D->host_buf_bytes = want;
     }
-    void* d_keys = D->host_buf;
-    void* d_tmp = static_cast<char*>(D->host_buf) + half;
+    void* d_keys = use_pool ? pool_buf : D->host_buf;
+    void* d_tmp = static_cast<char*>(d_keys) + half;
+    struct PoolGuard { void* p; hipStream_t s; ~PoolGuard() { if (p) (void)hipFreeAsync(p, s); } } pool_guard{pool_nofree ? nullptr : pool_buf, s};
     if ((e = hipMemcpyAsync(d_keys, host_data, bytes, hipMemcpyHostToDevice, s)) != hipSuccess) { (void)hipStreamSynchronize(s); return done(fail(RDST_ERR_HIP, "H2D", e)); }
+    if (pool_sync) (void)hipStreamSynchronize(s);
+    if (host_debug) {
+        fprintf(stderr, "[host] len=%llu elem=%u keys=[%p,%p) tmp=[%p,%p) ws=[%p,%p)\n", (unsigned long long)len, elem_bytes, d_keys,
+                (void*)(static_cast<char*>(d_keys) + bytes), d_tmp, (void*)(static_cast<char*>(d_tmp) + bytes), D->ws,
+                (void*)(static_cast<char*>(D->ws) + D->ws_bytes));
+        fflush(stderr);
+    }
     rc = rdst_hip_sort_device(d_keys, d_tmp, len, elem_bytes, kind, levels, s);
+    if (host_debug) {
+        fprintf(stderr, "[host]   after enqueue: ws=[%p,%p) rc=%d\n", D->ws, (void*)(static_cast<char*>(D->ws) + D->ws_bytes), rc);
+        fflush(stderr);
+    }
     if (rc == RDST_OK) rc = rdst_hip_device_status(s);
     if (rc != RDST_OK) { (void)hipStreamSynchronize(s); return done(rc); }
     // the host buffer is written only now, after the device reported success

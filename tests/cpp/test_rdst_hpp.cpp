@@ -16,8 +16,13 @@ static bool same_bits(const std::vector<T>& a, const std::vector<T>& b) {
     return a.size() == b.size() && (a.empty() || std::memcmp(a.data(), b.data(), a.size() * sizeof(T)) == 0);
 }
 
+// one line per check on stderr, flushed, BEFORE the call: an uncaught rdst::Error aborts the process at the first
+// throw, and the log then names the call that threw (type, length) and everything that ran before it
+#define PROGRESS(what, n) do { std::fprintf(stderr, "[check] %s n=%zu\n", what, (std::size_t)(n)); std::fflush(stderr); } while (0)
+
 template <typename T>
 static int check_int(std::size_t n, unsigned seed) {
+    PROGRESS(__PRETTY_FUNCTION__, n);
     std::mt19937_64 rng(seed);
     std::vector<T> v(n);
     for (auto& x : v) x = static_cast<T>(rng());
@@ -29,6 +34,7 @@ static int check_int(std::size_t n, unsigned seed) {
 
 template <typename T, typename U>
 static int check_float(std::size_t n, unsigned seed) {
+    PROGRESS(__PRETTY_FUNCTION__, n);
     std::mt19937_64 rng(seed);
     std::vector<T> v(n);
     for (auto& x : v) { U b = static_cast<U>(rng()); std::memcpy(&x, &b, sizeof b); }  // any bit pattern
@@ -48,6 +54,7 @@ struct LargeStruct {
 };
 
 static int check_struct(std::size_t n, unsigned seed) {
+    PROGRESS("check_struct", n);
     std::mt19937_64 rng(seed);
     std::vector<LargeStruct> v(n);
     for (std::size_t i = 0; i < n; ++i) {
@@ -66,6 +73,7 @@ static int check_struct(std::size_t n, unsigned seed) {
 
 template <std::size_t N>
 static int check_bytes(std::size_t n, unsigned seed) {  // [u8; N] sorts lexicographically (src/radix_sort.rs:221-229)
+    PROGRESS(__PRETTY_FUNCTION__, n);
     std::mt19937_64 rng(seed);
     std::vector<std::array<std::uint8_t, N>> v(n);
     for (auto& a : v) for (auto& b : a) b = static_cast<std::uint8_t>(rng() % 5 ? rng() : 0);
