@@ -242,7 +242,8 @@ int rdst_hip_profile_run_stages(int run, uint32_t* stages_out, uint32_t capacity
  * take the hybrid route — the device form of rdst's own MSD-then-Lsb route at this size (SURVEY.md §3.1;
  * src/tuners/standard_tuner.rs:46-62 picks by length and counts, too).  enabled == 0: LSD route always;
  * enabled == 2: hybrid route, but 4-byte keys also use the generic ranked in-LDS sort instead of the
- * counting sort by value (A/B and tests).
+ * counting sort by value; enabled == 3: counting sort, but pass L-1 hands it whole keys instead of the 16-bit low
+ * halves it normally leaves in the workspace (A/B and tests).
  * min_len == 0 keeps the built-in threshold (2^28).  Results are identical on either route.
  * Not part of the reference surface. */
 int rdst_hip_set_hybrid(int enabled, uint64_t min_len);

@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librdst_hip.so")
+# RDST_HIP_LIB: another build of the same library (tools/ A/B runs only; tests and bench use the in-tree one)
+LIB_PATH = os.environ.get("RDST_HIP_LIB") or os.path.join(_HERE, "librdst_hip.so")
 
 RDST_KEY_UNSIGNED, RDST_KEY_SIGNED, RDST_KEY_FLOAT, RDST_KEY_BYTES_BE = 0, 1, 2, 3
 RDST_OK = 0

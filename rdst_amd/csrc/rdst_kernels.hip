@@ -401,6 +401,9 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const K* __restrict_
 // hybrid route anyway.  The flag sends the sort down the LSD route.
 // ------------------------------------------------------------------------------------------
 constexpr int H16_WORDS = H16_BINS / 2;
+#ifndef RDST_H16_BATCH
+#define RDST_H16_BATCH 4
+#endif
 
 template <typename K, int VEC, bool MAPPED>
 __global__ __launch_bounds__(HIST_THREADS) void hist16_kernel(const K* __restrict__ keys, uint64_t n, K neg, K pos,
@@ -443,26 +446,27 @@ __global__ __launch_bounds__(HIST_THREADS) void hist16_kernel(const K* __restric
     struct alignas(sizeof(K) * VEC) V { K e[VEC]; };
     uint64_t i = p_begin + (uint64_t)tid * VEC;
     constexpr uint64_t STRIDE = (uint64_t)HIST_THREADS * VEC;
-    constexpr uint64_t S4 = 4 * STRIDE;  // one batch: four vectors per lane
+    constexpr int NB = RDST_H16_BATCH;       // vectors per lane and batch
+    constexpr uint64_t S4 = NB * STRIDE;  // one batch
     const uint64_t lane_rest = (uint64_t)(63 - (tid & 63)) * VEC;
     // full batches of this wave (while its LAST lane still has one: whole waves enter and leave together)
-    const uint64_t need = i + lane_rest + 3 * STRIDE + VEC;
+    const uint64_t need = i + lane_rest + (NB - 1) * STRIDE + VEC;
     const uint64_t nb = need <= p_end ? (p_end - need) / S4 + 1 : 0;
     // Loads run one batch ahead of the counting (two register sets, ping-pong): with one block per CU a
     // wave that waits for its own loads before counting leaves the memory pipeline idle meanwhile.
-    auto load = [&](V (&v)[4], K (&edge)[4], uint64_t at) {
+    auto load = [&](V (&v)[NB], K (&edge)[NB], uint64_t at) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const V*>(keys + at + u * STRIDE);
+        for (int u = 0; u < NB; ++u) v[u] = *reinterpret_cast<const V*>(keys + at + u * STRIDE);  // (non-temporal loads: 0.89 instead of 0.80 ms)
         // key before my vector = last key of the lane below; only lane 0 of a wave has to fetch it
 #pragma unroll
-        for (int u = 0; u < 4; ++u) edge[u] = ((tid & 63) == 0 && at + u * STRIDE > 0) ? keys[at + u * STRIDE - 1] : (K)0;
+        for (int u = 0; u < NB; ++u) edge[u] = ((tid & 63) == 0 && at + u * STRIDE > 0) ? keys[at + u * STRIDE - 1] : (K)0;
     };
-    auto proc = [&](V (&v)[4], K (&edge)[4], uint64_t at) {
+    auto proc = [&](V (&v)[NB], K (&edge)[NB], uint64_t at) {
         const uint32_t b0 = (uint32_t)(mapped(v[0].e[0]) >> (W - 16));
         const bool careful = __all((int)(b0 == (uint32_t)__builtin_amdgcn_readfirstlane((int)b0))) != 0;
         auto batch = [&](bool c) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NB; ++u) {
                 K before = lane_below<K>(mapped(v[u].e[VEC - 1]));
                 if ((tid & 63) == 0) before = (at + u * STRIDE > 0) ? mapped(edge[u]) : (K)0;
 #pragma unroll
@@ -473,8 +477,8 @@ __global__ __launch_bounds__(HIST_THREADS) void hist16_kernel(const K* __restric
         else batch(false);
     };
     {
-        V va[4], vb[4];
-        K ea[4], eb[4];
+        V va[NB], vb[NB];
+        K ea[NB], eb[NB];
         uint64_t b = 0;
         if (nb) load(va, ea, i);
         while (b + 2 <= nb) {  // va holds batch b
@@ -625,6 +629,7 @@ struct ScanArgs {
     const uint32_t* inversion;
     uint64_t n, hist_piece;
     uint32_t levels, allow_skip, level_lo, level_hi, hist_grid, tile, use_chains;
+    uint32_t halves;  // hybrid route hands K4 the 16-bit halves pass L-1 writes: that pass must run even if its level is trivial
 };
 
 constexpr int SCAN_GROUPS = 4;  // levels handled side by side, 256 threads (one per digit) each
@@ -674,7 +679,8 @@ __global__ __launch_bounds__(256 * SCAN_GROUPS) void scan_kernel(ScanArgs a) {
         a.plan->local_sort = hybrid && !already_sorted ? 1u : 0u;
         for (uint32_t l = 0; l < MAX_LEVELS; ++l) {
             const bool active = l >= level_lo && l < a.level_hi && l < a.levels;
-            const bool skip = !active || already_sorted || (a.allow_skip && s_trivial[l]);
+            const bool needed = hybrid && a.halves && l + 1 == a.levels;
+            const bool skip = !active || already_sorted || (a.allow_skip && s_trivial[l] && !needed);
             a.plan->skip[l] = s_skip[l] = skip ? 1u : 0u;
             a.plan->src_is_tmp[l] = in_tmp;
             uint32_t mode = CHAIN_ONE;
@@ -887,9 +893,13 @@ template <typename V> struct ValBytes { static constexpr int value = (int)sizeof
 template <> struct ValBytes<NoVal> { static constexpr int value = 0; };
 
 // V: payload carried with every key (key-value sort: 4- or 8-byte values, whole tile staged), or NoVal
-template <typename K, typename S, int KPT, int NWAVES, int STAGES, bool MAPPED, bool NARROW, typename V = NoVal>
+// OUT16 (4-byte keys, NARROW, the hybrid route's pass on level L-1 only): after this pass a key's position tells
+// its top 16 bits (it lies in bucket b = [bstart[b], bstart[b+1])), so the pass stores only the low halves of the
+// MAPPED keys, as a 16-bit array `out16` in the workspace, and K4 reads those: 2 bytes per key less written, 2 less
+// read.  Decided at run time (the route is the device's choice): on the LSD route the same kernel stores whole keys.
+template <typename K, typename S, int KPT, int NWAVES, int STAGES, bool MAPPED, bool NARROW, typename V = NoVal, bool OUT16 = false>
 __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8, NWAVES * 64 * KPT * ((int)sizeof(K) + ValBytes<V>::value) / STAGES) * NWAVES + 3) / 4) void onesweep_kernel(
-    K* __restrict__ buf_keys, K* __restrict__ buf_tmp, V* __restrict__ buf_vals, V* __restrict__ buf_vtmp, uint64_t n, int level,
+    K* __restrict__ buf_keys, K* __restrict__ buf_tmp, V* __restrict__ buf_vals, V* __restrict__ buf_vtmp, uint16_t* __restrict__ out16, uint64_t n, int level,
     const uint64_t* __restrict__ cbase /* [CHAINS][256] of this level */, S* __restrict__ status /* [rows][256] of this level */,
     S* __restrict__ status_near /* same shape: the copy that stays in the writer's L2 */,
     const LevelChains* __restrict__ chains /* of this level */, uint32_t* __restrict__ ticket /* of this level: [CHAINS + 1][TICKET_STRIDE], per chain, then the mask of chains handed out */,
@@ -919,11 +929,13 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8,
     constexpr bool HAS_V = ValBytes<V>::value != 0;
     constexpr bool FAR_X4 = RDST_FAR_X4 && sizeof(S) == 4;  // 64-bit status words (n >= 2^30) keep the per-word stores
     static_assert(!HAS_V || STAGES == 1, "payloads are staged with the whole tile");
+    static_assert(!OUT16 || (NARROW && !HAS_V && sizeof(K) == 4), "16-bit hand-off: 4-byte keys, 32-bit offsets");
     // whole tile staged: the running slots of step 5 count in bytes of the staging buffer (one
     // shift-add per key to the LDS address); two stages: in keys (16-bit packing)
     constexpr uint32_t SLOT_UNIT = STAGES == 1 ? (uint32_t)sizeof(K) : 1u;
 
     if (plan->skip[level]) return;
+    const bool halves = OUT16 && plan->route == ROUTE_HYBRID;  // block-uniform
     const bool from_tmp = plan->src_is_tmp[level] != 0;
     const K* __restrict__ src = from_tmp ? buf_tmp : buf_keys;
     K* __restrict__ dst = from_tmp ? buf_keys : buf_tmp;
@@ -1319,6 +1331,12 @@ ranked:
                     const uint32_t g = dd[i] + p * (uint32_t)sizeof(K);  // byte offset, < 2^32
                     const bool ok = g < (uint32_t)n * (uint32_t)sizeof(K);
                     bad |= !ok && (full || p < valid);
+                    if constexpr (OUT16) {
+                        if (halves) {  // low half of the mapped key, at the same element index of the 16-bit array
+                            if (ok && (full || p < valid)) *reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned char*>(out16) + (g >> 1)) = (uint16_t)kk[i];
+                            continue;
+                        }
+                    }
                     if (ok && (full || p < valid)) {
                         *reinterpret_cast<K*>(reinterpret_cast<unsigned char*>(dst) + g) = out;
                         if constexpr (HAS_V) {  // same element index, in the value array's stride
@@ -1463,13 +1481,20 @@ constexpr int local_tile(size_t key_bytes) { return local_waves(key_bytes) * 64 
 constexpr size_t local_lds_bytes(size_t key_bytes) { return (size_t)local_waves(key_bytes) * 1024 + 64 + key_bytes * local_tile(key_bytes); }
 
 template <typename K, int NWAVES, int KPT, bool MAPPED>
-__device__ __forceinline__ void local_sort_bucket(K* __restrict__ buf, const uint32_t bucket, const uint32_t start, const uint32_t cnt,
+__device__ __forceinline__ void local_sort_bucket(K* __restrict__ buf, const uint16_t* __restrict__ src16 /* nullable: low halves of the mapped keys */,
+                                                  const uint32_t bucket, const uint32_t start, const uint32_t cnt,
                                                   uint32_t* __restrict__ err, K neg, K pos, uint32_t flags) {
     constexpr int BLOCK = NWAVES * 64, TILE = BLOCK * KPT, W = sizeof(K) * 8, LOCAL = (int)sizeof(K) - 2;
     constexpr uint32_t SLOT_UNIT = (uint32_t)sizeof(K);  // running slots count in bytes of the staging buffer
     static_assert(BLOCK >= RADIX && TILE <= 65536, "one thread per digit / 16-bit run indices");
-    if (cnt <= 1) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (cnt <= 1) {
+        if (sizeof(K) == 4 && src16 && cnt == 1 && tid == 0) {  // the key exists only as its low half
+            const K m = (K)((K)bucket << (W - 16)) | (K)src16[start];
+            buf[start] = MAPPED ? unmap_key<K>(m, neg, pos) : m;
+        }
+        return;
+    }
     if (cnt > (uint32_t)TILE) {  // the route test rules it out; never sort a truncated bucket
         if (tid == 0) atomicOr(err, ERR_LOCAL_OVERFLOW);
         return;
@@ -1493,8 +1518,13 @@ __device__ __forceinline__ void local_sort_bucket(K* __restrict__ buf, const uin
             K v = sentinel;
             if (i < rounds) {  // block-uniform
                 const uint32_t idx = wbase + i * 64;
-                const K raw = tsrc[idx < cnt ? idx : cnt - 1];
-                if (idx < cnt) v = MAPPED ? map_key<K>(raw, neg, pos) : raw;
+                const uint32_t at = idx < cnt ? idx : cnt - 1;
+                if (sizeof(K) == 4 && src16) {  // block-uniform
+                    if (idx < cnt) v = (K)((K)bucket << (W - 16)) | (K)src16[start + at];
+                } else {
+                    const K raw = tsrc[at];
+                    if (idx < cnt) v = MAPPED ? map_key<K>(raw, neg, pos) : raw;
+                }
             }
             mk[i] = v;
         }
@@ -1662,13 +1692,14 @@ __device__ __forceinline__ void local_sort_bucket(K* __restrict__ buf, const uin
 template <typename K, int NWAVES, int KPT, bool MAPPED>
 __global__ __launch_bounds__(NWAVES * 64, (sizeof(K) <= 4 ? 2 : 1) * NWAVES / 4) void local_sort_kernel(
     K* __restrict__ buf_keys, K* __restrict__ buf_tmp, const uint32_t* __restrict__ bstart, const Plan* __restrict__ plan,
-    uint32_t* __restrict__ err, K neg, K pos, uint32_t flags, const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count) {
+    uint32_t* __restrict__ err, K neg, K pos, uint32_t flags, const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count,
+    const uint16_t* __restrict__ src16) {
     if (!plan->local_sort) return;
     K* __restrict__ buf = plan->result_in_tmp ? buf_tmp : buf_keys;
     if (list == nullptr) {
         const uint32_t bucket = blockIdx.x;
         const uint32_t start = bstart[bucket];
-        local_sort_bucket<K, NWAVES, KPT, MAPPED>(buf, bucket, start, bstart[bucket + 1] - start, err, neg, pos, flags);
+        local_sort_bucket<K, NWAVES, KPT, MAPPED>(buf, src16, bucket, start, bstart[bucket + 1] - start, err, neg, pos, flags);
         return;
     }
     const uint32_t todo = *list_count;
@@ -1676,7 +1707,7 @@ __global__ __launch_bounds__(NWAVES * 64, (sizeof(K) <= 4 ? 2 : 1) * NWAVES / 4)
     for (uint32_t e = blockIdx.x; e < todo; e += gridDim.x) {
         const uint32_t bucket = list[e];
         const uint32_t start = bstart[bucket];
-        local_sort_bucket<K, NWAVES, KPT, MAPPED>(buf, bucket, start, bstart[bucket + 1] - start, err, neg, pos, flags);
+        local_sort_bucket<K, NWAVES, KPT, MAPPED>(buf, src16, bucket, start, bstart[bucket + 1] - start, err, neg, pos, flags);
         __syncthreads();  // the next bucket reuses the LDS
     }
 }
@@ -1704,10 +1735,12 @@ __device__ __forceinline__ uint32_t nibble_sum(uint32_t x, uint32_t acc) {
     return __builtin_amdgcn_sad_u8(t, 0u, acc);  // acc + the four byte sums
 }
 
-template <int BLOCK, bool MAPPED>
+// FROM16: the bucket arrives as the low halves of the mapped keys (pass L-1 stored only those, see OUT16 of K3)
+template <int BLOCK, bool MAPPED, bool FROM16>
 __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 8 : 6) void local_count_sort_kernel(
-    uint32_t* __restrict__ buf_keys, uint32_t* __restrict__ buf_tmp, const uint32_t* __restrict__ bstart, const Plan* __restrict__ plan,
-    uint32_t* __restrict__ err, uint32_t neg, uint32_t pos, uint32_t* __restrict__ list, uint32_t* __restrict__ list_count) {
+    uint32_t* __restrict__ buf_keys, uint32_t* __restrict__ buf_tmp, const uint16_t* __restrict__ src16, const uint32_t* __restrict__ bstart,
+    const Plan* __restrict__ plan, uint32_t* __restrict__ err, uint32_t neg, uint32_t pos, uint32_t* __restrict__ list,
+    uint32_t* __restrict__ list_count) {
     constexpr int MAXR = (COUNT_TILE + BLOCK - 1) / BLOCK;
     constexpr int VPT = H16_BINS / BLOCK, WPT = VPT / 8;  // values / counter words per thread
     constexpr int LOG_VPT = BLOCK == 1024 ? 6 : (BLOCK == 512 ? 7 : 8);
@@ -1716,8 +1749,16 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 8 : 6) void local_count_sort
     uint32_t* __restrict__ buf = plan->result_in_tmp ? buf_tmp : buf_keys;
     const uint32_t bucket = blockIdx.x;
     const uint32_t start = bstart[bucket], cnt = bstart[bucket + 1] - start;
-    if (cnt <= 1) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (cnt <= 1) {
+        if constexpr (FROM16) {  // the key exists only as its low half: put it back together
+            if (cnt == 1 && tid == 0) {
+                const uint32_t m = (bucket << 16) | (uint32_t)src16[start];
+                buf[start] = MAPPED ? unmap_key<uint32_t>(m, neg, pos) : m;
+            }
+        }
+        return;
+    }
     if (cnt > (uint32_t)COUNT_TILE) {
         if (tid == 0) atomicOr(err, ERR_LOCAL_OVERFLOW);
         return;
@@ -1728,12 +1769,13 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 8 : 6) void local_count_sort
     uint16_t* out16 = reinterpret_cast<uint16_t*>(smem);                   // [cnt] sorted low halves (aliases both, later)
     uint32_t* s_wsum = reinterpret_cast<uint32_t*>(smem + 32768 + 16384);  // [16] wave sums, [16] overflow flag
     __builtin_amdgcn_s_setprio(RDST_PRIO_LOAD);
-    const uint32_t* tsrc = buf + start;
     uint32_t kv[MAXR];
 #pragma unroll
     for (int i = 0; i < MAXR; ++i) {
         const uint32_t idx = (uint32_t)tid + i * BLOCK;
-        kv[i] = tsrc[idx < cnt ? idx : cnt - 1];
+        const uint32_t at = start + (idx < cnt ? idx : cnt - 1);
+        if constexpr (FROM16) kv[i] = src16[at];
+        else kv[i] = buf[at];
     }
 #pragma unroll
     for (int k = 0; k < WPT; ++k) cnt4[k * BLOCK + tid] = 0;
@@ -1746,7 +1788,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 8 : 6) void local_count_sort
     for (int i = 0; i < MAXR; ++i) {
         const uint32_t idx = (uint32_t)tid + i * BLOCK;
         if (idx < cnt) {
-            const uint32_t v = (MAPPED ? map_key<uint32_t>(kv[i], neg, pos) : kv[i]) & 0xFFFFu;
+            const uint32_t v = FROM16 ? kv[i] : ((MAPPED ? map_key<uint32_t>(kv[i], neg, pos) : kv[i]) & 0xFFFFu);
             const uint32_t sh = (v & 7u) * 4u;
             const uint32_t old = atomicAdd(&cnt4[word_of(v)], 1u << sh);
             const uint32_t mine = (old >> sh) & 15u;
@@ -1906,6 +1948,16 @@ __global__ __launch_bounds__(256) void stream_read_kernel(const uint4* __restric
     if (acc == 0x9E3779B9u) *sink = acc;  // keeps the loads alive; practically never taken
 }
 
+// Status rows of the levels only the LSD route uses: cleared after the route decision, and only if it fell that way
+__global__ __launch_bounds__(256) void clear_unless_hybrid_kernel(const Plan* __restrict__ plan, uint4* __restrict__ a, uint64_t na, uint4* __restrict__ b,
+                                                                  uint64_t nb) {
+    if (plan->route == ROUTE_HYBRID) return;
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    const uint4 z = {0, 0, 0, 0};
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < na; i += stride) a[i] = z;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nb; i += stride) b[i] = z;
+}
+
 __global__ void raise_error_kernel(uint32_t* err, uint32_t bits) { atomicOr(err, bits); }  // rdst_hip_debug_raise_device_error
 
 // K6: one level's histogram + "digit sequence has an inversion" flag
@@ -1983,6 +2035,7 @@ struct Tuning {
     bool small_sort = true;
     bool hybrid = true;                 // consider the hybrid route at all
     bool count_sort = true;             // 4-byte keys: K4 as a counting sort by value (false: the generic ranked passes)
+    bool halves = true;                 // 4-byte keys: pass L-1 hands K4 the low halves only (16-bit array in the workspace)
     uint64_t hybrid_min_len = 1ull << 28;  // below this the buckets are too small for one workgroup each to pay off
 };
 uint32_t g_ablate = 0;  // only ever set by the RDST_EXPERIMENTS build
@@ -2025,7 +2078,7 @@ struct Layout {
     uint32_t levels, tile, status_bytes;  // status_bytes: 4 or 8 per word
     uint64_t tiles;
     size_t off_err, off_tickets, off_plan, off_hpos, off_hpair, off_h16, off_hpos16, off_status, off_status_near, zero_bytes, off_hist, off_base,
-        off_cbase, off_chains, off_bstart, off_fblist, total;
+        off_cbase, off_chains, off_bstart, off_fblist, off_halves, total;
 };
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -2035,7 +2088,7 @@ int tile_keys(int cfg, uint32_t elem_bytes) {
     return p.nwaves * 64 * kpt_for(p.kpt8, elem_bytes);
 }
 
-Layout make_layout(uint64_t n, uint32_t elem_bytes, uint32_t levels, int cfg, uint32_t tile_override = 0) {
+Layout make_layout(uint64_t n, uint32_t elem_bytes, uint32_t levels, int cfg, uint32_t tile_override = 0, bool want_halves = false) {
     Layout L{};
     L.levels = levels;
     L.tile = tile_override ? tile_override : (uint32_t)tile_keys(cfg, elem_bytes);
@@ -2060,6 +2113,9 @@ Layout make_layout(uint64_t n, uint32_t elem_bytes, uint32_t levels, int cfg, ui
     o = align_up(o, 16);
     L.off_bstart = o; o += sizeof(uint32_t) * ((size_t)H16_BINS + 4);     // hybrid route: bucket starts
     L.off_fblist = o; o += sizeof(uint32_t) * (size_t)H16_BINS;           // buckets left to the generic local sort (count: header word 3)
+    o = align_up(o, 256);
+    L.off_halves = o;                                                       // hybrid route, 4-byte keys: low halves between pass L-1 and K4
+    if (want_halves) o += align_up(sizeof(uint16_t) * n, 256);
     L.total = align_up(o, 256);
     return L;
 }
@@ -2130,6 +2186,11 @@ int prof_mark(DeviceState& D, hipStream_t s, uint32_t kind = 0) {
     HIP_TRY(hipEventRecord(D.prof_events[D.prof_used++], s));
     D.prof_runs.back().count = D.prof_used - D.prof_runs.back().begin;
     return RDST_OK;
+}
+
+bool hybrid_eligible(uint64_t n, size_t key_bytes) {
+    return g_tuning.hybrid && (key_bytes == 4 || key_bytes == 8) && n >= g_tuning.hybrid_min_len &&
+           n <= (uint64_t)H16_BINS * local_tile(key_bytes) && n < (1ull << 32);
 }
 
 // hipFuncSetAttribute acts on the CURRENT device's copy of the function: remember (device, kernel) -> bytes
@@ -2208,7 +2269,7 @@ constexpr int COUNT_THREADS = 1024;
 // over the (normally empty) list of buckets it could not take; 8-byte keys: the generic one over all buckets.
 template <typename K>
 int launch_local_sort(K* keys, K* tmp, const uint32_t* bstart, const Plan* plan, uint32_t* err, KeyMap km, uint32_t* list,
-                      uint32_t* list_count, int cus, hipStream_t s) {
+                      uint32_t* list_count, const uint16_t* src16, int cus, hipStream_t s) {
     constexpr int NW = local_waves(sizeof(K)), KPT = local_kpt(sizeof(K));
     constexpr size_t lds = local_lds_bytes(sizeof(K));
     const bool mapped = km.neg != 0 || km.pos != 0;
@@ -2217,13 +2278,15 @@ int launch_local_sort(K* keys, K* tmp, const uint32_t* bstart, const Plan* plan,
     if constexpr (sizeof(K) == 4) {
         if (counting) {
             constexpr size_t clds = count_lds_bytes();
-            if (mapped) {
-                if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_count_sort_kernel<COUNT_THREADS, true>), clds)) return rc;
-                hipLaunchKernelGGL((local_count_sort_kernel<COUNT_THREADS, true>), dim3(H16_BINS), dim3(COUNT_THREADS), clds, s, keys, tmp, bstart, plan, err, (uint32_t)km.neg, (uint32_t)km.pos, list, list_count);
-            } else {
-                if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_count_sort_kernel<COUNT_THREADS, false>), clds)) return rc;
-                hipLaunchKernelGGL((local_count_sort_kernel<COUNT_THREADS, false>), dim3(H16_BINS), dim3(COUNT_THREADS), clds, s, keys, tmp, bstart, plan, err, (uint32_t)km.neg, (uint32_t)km.pos, list, list_count);
-            }
+#define RDST_COUNT(MAPPED, FROM16)                                                                                                   \
+    do {                                                                                                                             \
+        if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_count_sort_kernel<COUNT_THREADS, MAPPED, FROM16>), clds)) return rc; \
+        hipLaunchKernelGGL((local_count_sort_kernel<COUNT_THREADS, MAPPED, FROM16>), dim3(H16_BINS), dim3(COUNT_THREADS), clds, s, keys, tmp, \
+                           src16, bstart, plan, err, (uint32_t)km.neg, (uint32_t)km.pos, list, list_count);                       \
+    } while (0)
+            if (src16) { if (mapped) RDST_COUNT(true, true); else RDST_COUNT(false, true); }
+            else { if (mapped) RDST_COUNT(true, false); else RDST_COUNT(false, false); }
+#undef RDST_COUNT
             HIP_TRY(hipGetLastError());
         }
     }
@@ -2231,21 +2294,21 @@ int launch_local_sort(K* keys, K* tmp, const uint32_t* bstart, const Plan* plan,
     const uint32_t* wl = counting ? list : nullptr;
     if (mapped) {
         if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_sort_kernel<K, NW, KPT, true>), lds)) return rc;
-        hipLaunchKernelGGL((local_sort_kernel<K, NW, KPT, true>), grid, dim3(NW * 64), lds, s, keys, tmp, bstart, plan, err, (K)km.neg, (K)km.pos, flags, wl, list_count);
+        hipLaunchKernelGGL((local_sort_kernel<K, NW, KPT, true>), grid, dim3(NW * 64), lds, s, keys, tmp, bstart, plan, err, (K)km.neg, (K)km.pos, flags, wl, list_count, src16);
     } else {
         if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_sort_kernel<K, NW, KPT, false>), lds)) return rc;
-        hipLaunchKernelGGL((local_sort_kernel<K, NW, KPT, false>), grid, dim3(NW * 64), lds, s, keys, tmp, bstart, plan, err, (K)km.neg, (K)km.pos, flags, wl, list_count);
+        hipLaunchKernelGGL((local_sort_kernel<K, NW, KPT, false>), grid, dim3(NW * 64), lds, s, keys, tmp, bstart, plan, err, (K)km.neg, (K)km.pos, flags, wl, list_count, src16);
     }
     HIP_TRY(hipGetLastError());
     return RDST_OK;
 }
 
-template <typename K, typename S, int KPT, int NWAVES, int STAGES, bool MAPPED, bool NARROW, typename V = NoVal>
+template <typename K, typename S, int KPT, int NWAVES, int STAGES, bool MAPPED, bool NARROW, typename V = NoVal, bool OUT16 = false>
 int launch_pass_t(K* keys, K* tmp, uint64_t n, int level, const Layout& L, char* ws, KeyMap km, int cus, hipStream_t s,
-                  V* vals = nullptr, V* vtmp = nullptr) {
+                  V* vals = nullptr, V* vtmp = nullptr, uint16_t* out16 = nullptr) {
     constexpr int TILE = NWAVES * 64 * KPT;
     size_t lds = (size_t)pass_lds_bytes(NWAVES, NARROW ? 4 : 8, ((int)sizeof(K) + ValBytes<V>::value) * (TILE / STAGES));
-    auto kernel = &onesweep_kernel<K, S, KPT, NWAVES, STAGES, MAPPED, NARROW, V>;
+    auto kernel = &onesweep_kernel<K, S, KPT, NWAVES, STAGES, MAPPED, NARROW, V, OUT16>;
 #ifdef RDST_EXPERIMENTS
     if (g_exp_lds_total > lds) lds = g_exp_lds_total;  // fewer blocks per CU
 #endif
@@ -2261,7 +2324,7 @@ int launch_pass_t(K* keys, K* tmp, uint64_t n, int level, const Layout& L, char*
     uint32_t* err = D->err_dev;
     (void)cus;
     const dim3 grid((uint32_t)L.tiles), block(NWAVES * 64);  // >= one block per tile of any chain split
-    hipLaunchKernelGGL((onesweep_kernel<K, S, KPT, NWAVES, STAGES, MAPPED, NARROW, V>), grid, block, lds, s, keys, tmp, vals, vtmp, n,
+    hipLaunchKernelGGL((onesweep_kernel<K, S, KPT, NWAVES, STAGES, MAPPED, NARROW, V, OUT16>), grid, block, lds, s, keys, tmp, vals, vtmp, out16, n,
                        level, cbase, status, status_near, chains, ticket, plan, err, (K)km.neg, (K)km.pos, g_ablate | (g_tuning.fast_rank ? RDST_FAST_RANK : 0u) | (g_tuning.fast_rank == 2 ? RDST_FAST_RANK_SELFTEST : 0u));
     HIP_TRY(hipGetLastError());
     return RDST_OK;
@@ -2281,10 +2344,22 @@ int launch_pass_s(int cfg, K* keys, K* tmp, uint64_t n, int level, const Layout&
     return fail(RDST_ERR_ARG, "pass config not built into this library (0 and 1 exist in the tools build only)");
 }
 
+// the shapes the 16-bit hand-off of the hybrid route is built for: the default pass shape of 4-byte keys below 2^30
 template <typename K>
-int launch_pass(int cfg, K* keys, K* tmp, uint64_t n, int level, const Layout& L, char* ws, KeyMap km, int cus, hipStream_t s) {
+bool halves_possible(int cfg, uint64_t n) { return sizeof(K) == 4 && cfg == 4 && n < (1ull << 30); }
+
+template <typename K>
+int launch_pass(int cfg, K* keys, K* tmp, uint64_t n, int level, const Layout& L, char* ws, KeyMap km, int cus, hipStream_t s,
+                uint16_t* out16 = nullptr) {
     const bool mapped = km.neg != 0 || km.pos != 0;
     const bool narrow = n * sizeof(K) < (1ull << 32);
+    if constexpr (sizeof(K) == 4) {
+        if (out16 && halves_possible<K>(cfg, n) && L.status_bytes == 4 && narrow) {
+            constexpr int KPT = kpt_for(11, sizeof(K));
+            return mapped ? launch_pass_t<K, uint32_t, KPT, 12, 1, true, true, NoVal, true>(keys, tmp, n, level, L, ws, km, cus, s, nullptr, nullptr, out16)
+                          : launch_pass_t<K, uint32_t, KPT, 12, 1, false, true, NoVal, true>(keys, tmp, n, level, L, ws, km, cus, s, nullptr, nullptr, out16);
+        }
+    }
     if (L.status_bytes == 4) {
         if (narrow) {
             return mapped ? launch_pass_s<K, uint32_t, true, true>(cfg, keys, tmp, n, level, L, ws, km, cus, s)
@@ -2349,7 +2424,12 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     }
     int cfg = g_tuning.pass_cfg;
     if (cfg < 0 || cfg >= kNumPassCfgs) cfg = default_cfg(sizeof(K), n);
-    const Layout L = make_layout(n, sizeof(K), LEVELS, cfg, HAS_V ? PAIR_WAVES * 64 * pair_kpt(sizeof(K), ValBytes<V>::value) : 0);
+    // Hybrid route (whole sorts of 4- and 8-byte keys, long enough that a bucket is worth a workgroup, short
+    // enough that 65 536 tiles can hold it): K1h counts the buckets, route_kernel decides.  If it says LSD,
+    // K1 runs as ever (the slice is then read twice for counting); if it says hybrid, K1 returns at once.
+    const bool try_hybrid = !HAS_V && hybrid_eligible(n, sizeof(K)) && level_lo == 0 && level_hi == (uint32_t)LEVELS && allow_skip && copy_back;
+    const bool halves = try_hybrid && g_tuning.halves && g_tuning.count_sort && halves_possible<K>(cfg, n);
+    const Layout L = make_layout(n, sizeof(K), LEVELS, cfg, HAS_V ? PAIR_WAVES * 64 * pair_kpt(sizeof(K), ValBytes<V>::value) : 0, halves);
     if (L.tiles >= (1ull << 31)) return fail(RDST_ERR_ARG, "len too large for one launch");
     rc = ensure_workspace(*D, L.total);
     if (rc) return rc;
@@ -2363,7 +2443,15 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     const size_t status_hi = L.off_status + (size_t)L.status_bytes * level_hi * L.tiles * RADIX;
     if (g_tuning.profiling) D->prof_runs.push_back({D->prof_used, 0});
     if ((rc = prof_mark(*D, s))) return rc;
-    if (level_lo == 0 && level_hi == (uint32_t)LEVELS) {
+    // hybrid-eligible sorts clear the rows of the two levels that route uses now and leave the others to a conditional
+    // kernel behind the route decision (1 B u32: 0.07 ms of clearing -> half)
+    const size_t level_rows = (size_t)L.status_bytes * L.tiles * RADIX;  // one level, one copy
+    const bool split_clear = try_hybrid && LEVELS > 2;
+    if (split_clear) {
+        HIP_TRY(hipMemsetAsync(ws, 0, L.off_status, s));
+        HIP_TRY(hipMemsetAsync(ws + L.off_status + level_rows * (LEVELS - 2), 0, level_rows * 2, s));
+        HIP_TRY(hipMemsetAsync(ws + L.off_status_near + level_rows * (LEVELS - 2), 0, level_rows * 2, s));
+    } else if (level_lo == 0 && level_hi == (uint32_t)LEVELS) {
         HIP_TRY(hipMemsetAsync(ws, 0, L.zero_bytes, s));  // header, count tables and both copies of the status rows are contiguous
     } else {
         HIP_TRY(hipMemsetAsync(ws, 0, L.off_status, s));
@@ -2393,13 +2481,7 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     const bool pair = g_tuning.chains && LEVELS >= 2 && level_hi > level_lo + 1;
     unsigned long long* hpair = reinterpret_cast<unsigned long long*>(ws + L.off_hpair);
     Plan* plan = reinterpret_cast<Plan*>(ws + L.off_plan);
-    // Hybrid route (whole sorts of 4- and 8-byte keys, long enough that a bucket is worth a workgroup, short
-    // enough that 65 536 tiles can hold it): K1h counts the buckets, route_kernel decides.  If it says LSD,
-    // K1 below runs as ever (the slice is then read twice for counting); if it says hybrid, K1 returns at once.
-    bool try_hybrid = false;
     if constexpr (!HAS_V && (sizeof(K) == 4 || sizeof(K) == 8)) {
-        try_hybrid = g_tuning.hybrid && level_lo == 0 && level_hi == (uint32_t)LEVELS && allow_skip && copy_back &&
-                     n >= g_tuning.hybrid_min_len && n <= (uint64_t)H16_BINS * local_tile(sizeof(K)) && n < (1ull << 32);
         if (try_hybrid) {
             uint32_t* overflow = reinterpret_cast<uint32_t*>(ws + L.off_err) + 2;
             uint32_t* h16 = reinterpret_cast<uint32_t*>(ws + L.off_h16);
@@ -2420,6 +2502,12 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
             ra.cap = (uint32_t)local_tile(sizeof(K));
             hipLaunchKernelGGL(route_kernel, dim3(1), dim3(1024), 0, s, ra);
             HIP_TRY(hipGetLastError());
+            if (split_clear) {
+                const uint64_t vecs = level_rows * (LEVELS - 2) / 16;  // rows are multiples of 1 KiB
+                hipLaunchKernelGGL(clear_unless_hybrid_kernel, dim3((uint32_t)D->cus * 4), dim3(256), 0, s, plan,
+                                   reinterpret_cast<uint4*>(ws + L.off_status), vecs, reinterpret_cast<uint4*>(ws + L.off_status_near), vecs);
+                HIP_TRY(hipGetLastError());
+            }
             if ((rc = prof_mark(*D, s, RDST_STAGE_ROUTE))) return rc;
         }
     }
@@ -2445,19 +2533,22 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     sa.hist_grid = (uint32_t)blocks;
     sa.tile = L.tile;
     sa.use_chains = g_tuning.chains ? 1u : 0u;
+    sa.halves = halves ? 1u : 0u;
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(256 * SCAN_GROUPS), 0, s, sa);
     HIP_TRY(hipGetLastError());
     if ((rc = prof_mark(*D, s, RDST_STAGE_SCAN))) return rc;
     for (uint32_t level = level_lo; level < level_hi; ++level) {
         if constexpr (HAS_V) rc = launch_pass_pairs<K, V>(keys, tmp, vals, vtmp, n, (int)level, L, ws, km, D->cus, s);
-        else rc = launch_pass<K>(cfg, keys, tmp, n, (int)level, L, ws, km, D->cus, s);
+        else rc = launch_pass<K>(cfg, keys, tmp, n, (int)level, L, ws, km, D->cus, s,
+                                 halves && level + 1 == (uint32_t)LEVELS ? reinterpret_cast<uint16_t*>(ws + L.off_halves) : nullptr);
         if (rc) return rc;
         if ((rc = prof_mark(*D, s, RDST_STAGE_PASS | (level << 8)))) return rc;
     }
     if constexpr (!HAS_V && (sizeof(K) == 4 || sizeof(K) == 8)) {
         if (try_hybrid) {
             rc = launch_local_sort<K>(keys, tmp, reinterpret_cast<const uint32_t*>(ws + L.off_bstart), plan, D->err_dev, km,
-                                      reinterpret_cast<uint32_t*>(ws + L.off_fblist), reinterpret_cast<uint32_t*>(ws + L.off_err) + 3, D->cus, s);
+                                      reinterpret_cast<uint32_t*>(ws + L.off_fblist), reinterpret_cast<uint32_t*>(ws + L.off_err) + 3,
+                                      halves ? reinterpret_cast<const uint16_t*>(ws + L.off_halves) : nullptr, D->cus, s);
             if (rc) return rc;
             if ((rc = prof_mark(*D, s, RDST_STAGE_LOCAL))) return rc;
         }
@@ -2569,6 +2660,7 @@ int rdst_hip_set_hybrid(int enabled, uint64_t min_len) {
     std::lock_guard<std::mutex> lock(g_mutex);
     g_tuning.hybrid = enabled != 0;
     g_tuning.count_sort = enabled != 2;  // 2: hybrid route with the generic local sort for every key width (A/B, tests)
+    g_tuning.halves = enabled != 3;      // 3: counting K4 reading whole keys (no 16-bit hand-off) (A/B, tests)
     g_tuning.hybrid_min_len = min_len ? min_len : (1ull << 28);
     return RDST_OK;
 }
@@ -2725,7 +2817,8 @@ uint64_t rdst_hip_workspace_bytes(uint64_t len, uint32_t elem_bytes) {
     if (elem_bytes != 1 && elem_bytes != 2 && elem_bytes != 4 && elem_bytes != 8 && elem_bytes != 16) return 0;
     int cfg = g_tuning.pass_cfg;
     if (cfg < 0 || cfg >= kNumPassCfgs) cfg = default_cfg(elem_bytes, len);
-    return make_layout(len, elem_bytes, elem_bytes, cfg).total;
+    const bool halves = elem_bytes == 4 && hybrid_eligible(len, 4) && g_tuning.halves && g_tuning.count_sort && cfg == 4 && len < (1ull << 30);
+    return make_layout(len, elem_bytes, elem_bytes, cfg, 0, halves).total;
 }
 
 int rdst_hip_sort_device(void* dev_keys, void* dev_tmp, uint64_t len, uint32_t elem_bytes, rdst_key_kind kind,

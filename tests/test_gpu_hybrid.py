@@ -14,11 +14,13 @@ pytestmark = pytest.mark.gpu
 TILE = {4: 16896, 8: 16384}  # K4 tile = largest bucket the hybrid route accepts
 
 
-@pytest.fixture(params=["count", "ranked"])
+@pytest.fixture(params=["count", "count_whole_keys", "ranked"])
 def hybrid(gpu, request):
-    """both forms of K4 for 4-byte keys: the counting sort by value (default) and the generic ranked passes
-    (what 8-byte keys always use, and the fallback for buckets whose counters overflow)"""
-    gpu.set_hybrid(True if request.param == "count" else 2, min_len=1)   # consider the route at every length (default: 2^28 and up)
+    """the forms of K4 for 4-byte keys: the counting sort by value fed with the 16-bit halves pass L-1 leaves in the
+    workspace (default), the same fed with whole keys, and the generic ranked passes (what 8-byte keys always use,
+    and the fallback for buckets whose counters overflow)"""
+    mode = {"count": True, "count_whole_keys": 3, "ranked": 2}[request.param]
+    gpu.set_hybrid(mode, min_len=1)   # consider the route at every length (default: 2^28 and up)
     yield gpu
     gpu.set_hybrid(True, 0)
     gpu.set_tuning()
