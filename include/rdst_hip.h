@@ -192,6 +192,25 @@ int rdst_hip_all_level_counts(const void* dev_keys, uint64_t len, uint32_t elem_
 int rdst_hip_scatter_level(const void* dev_src, void* dev_dst, uint64_t len, uint32_t elem_bytes,
                            rdst_key_kind kind, uint32_t level, uint64_t* counts_out, void* stream);
 
+/* Sharded route (RDST_ALGO_GPU_SHARDED), device-side steps; the collectives between them are the caller's (RCCL through
+ * torch.distributed in rdst_amd/sharded.py, or a shim's own ncclAllGather / ncclSend+ncclRecv: INTEGRATION.md).  The
+ * reference's analogues are the MSD split of src/sorter.rs:131-138 and the tile -> bucket regrouping of
+ * src/sorts/recombinating_sort.rs:68-88.
+ *
+ * rdst_hip_split_top_level_device: ONE stable pass on the most significant level, dev_src -> dev_dst (dev_src is only
+ * read), i.e. the shard grouped by top digit, hence by owner rank (owners are contiguous digit ranges).  The 256 digit
+ * counts are left in DEVICE memory (dev_counts, 256 x u64) for the all-gather.  Asynchronous: nothing blocks, the
+ * histogram counts that one level only; failures surface in rdst_hip_device_status.
+ *
+ * rdst_hip_split_top16_device: the fallback when one top digit holds more than a rank's share: two
+ * stable passes (levels L-2, L-1; dev_tmp is scratch) leave dev_keys ordered by the top 16 bits of the mapped key, IN
+ * PLACE, and dev_counts16 (65 536 x u64, device) receives the bucket lengths — owners are then contiguous ranges of
+ * 16-bit prefixes.  Asynchronous.  Keys of at least two bytes. */
+int rdst_hip_split_top_level_device(const void* dev_src, void* dev_dst, uint64_t len, uint32_t elem_bytes,
+                                    rdst_key_kind kind, uint64_t* dev_counts, void* stream);
+int rdst_hip_split_top16_device(void* dev_keys, void* dev_tmp, uint64_t len, uint32_t elem_bytes,
+                                rdst_key_kind kind, uint64_t* dev_counts16, void* stream);
+
 /* Replaces `Tuner::pick_algorithm` (src/tuner.rs:33-35) for the stock tuners: pure
  * integer decision tables, host only.  counts has 256 entries (src/sorter.rs:67-76).
  * gpu_min_len is read only by RDST_TUNER_GPU.  For host slices the device route starts to win at

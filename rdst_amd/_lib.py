@@ -24,6 +24,8 @@ SYMBOLS = (
     "rdst_hip_level_counts",
     "rdst_hip_all_level_counts",
     "rdst_hip_scatter_level",
+    "rdst_hip_split_top_level_device",
+    "rdst_hip_split_top16_device",
     "rdst_pick_algorithm",
     "rdst_hip_workspace_bytes",
     "rdst_hip_set_tuning",
@@ -91,6 +93,8 @@ def load():
     lib.rdst_hip_level_counts.argtypes = [vp, u64, u32, ci, u32, u64p, u8p, u8p, u8p, vp]
     lib.rdst_hip_all_level_counts.argtypes = [vp, u64, u32, ci, u32, u64p, vp]
     lib.rdst_hip_scatter_level.argtypes = [vp, vp, u64, u32, ci, u32, u64p, vp]
+    lib.rdst_hip_split_top_level_device.argtypes = [vp, vp, u64, u32, ci, vp, vp]
+    lib.rdst_hip_split_top16_device.argtypes = [vp, vp, u64, u32, ci, vp, vp]
     lib.rdst_pick_algorithm.argtypes = [ci, ctypes.POINTER(TuningParamsC), u64p, u64]
     lib.rdst_hip_workspace_bytes.argtypes = [u64, u32]
     lib.rdst_hip_workspace_bytes.restype = u64

@@ -254,7 +254,8 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const K* __restrict_
                                                             unsigned long long* __restrict__ hpos /* [LEVELS][CHAINS][256]: counts per position range */,
                                                             unsigned long long* __restrict__ hpair /* [LEVELS][CHAINS][256]: counts per group of the previous digit (PAIR) */,
                                                             uint32_t* __restrict__ inversion /* set if keys[i-1] > keys[i] anywhere */,
-                                                            const Plan* __restrict__ plan /* nullable: the hybrid route has its own counts (K1h) */) {
+                                                            const Plan* __restrict__ plan /* nullable: the hybrid route has its own counts (K1h) */,
+                                                            int base_level /* table row and digit of this kernel's level 0 (one-level counts of a single pass: LEVELS == 1) */) {
     using P = HistPlan<LEVELS, PAIR>;
     if (plan && plan->route == ROUTE_HYBRID) return;
     constexpr int COPIES = P::COPIES, PCOPIES = P::PCOPIES, WORDS = P::WORDS;
@@ -287,9 +288,10 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const K* __restrict_
 #endif
 #pragma unroll
         for (int l = 0; l < P::PLAIN_LEVELS; ++l) {
-            uint32_t* w = &mine[(l * RADIX + digit_of(m, l * 8)) * COPIES];
+            const uint32_t dg = digit_of(m, (l + base_level) * 8);
+            uint32_t* w = &mine[(l * RADIX + dg) * COPIES];
             if (PAIR || !careful) atomicAdd(w, 1u);
-            else if (COPIES >= 32 || __all((int)(digit_of(m, l * 8) == (uint32_t)__builtin_amdgcn_readfirstlane((int)digit_of(m, l * 8)))) == 0) atomicAdd(w, 1u);
+            else if (COPIES >= 32 || __all((int)(dg == (uint32_t)__builtin_amdgcn_readfirstlane((int)dg))) == 0) atomicAdd(w, 1u);
             else if ((tid & 63) == 0) atomicAdd(w, 64u);
         }
 #pragma unroll
@@ -382,7 +384,7 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const K* __restrict_
                 c += cg;
             }
         }
-        if (c) atomicAdd(&hpos[((size_t)l * CHAINS + range) * RADIX + d], (unsigned long long)c);
+        if (c) atomicAdd(&hpos[((size_t)(l + base_level) * CHAINS + range) * RADIX + d], (unsigned long long)c);
     }
 }
 
@@ -1958,6 +1960,28 @@ __global__ __launch_bounds__(256) void clear_unless_hybrid_kernel(const Plan* __
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nb; i += stride) b[i] = z;
 }
 
+// Sharded route, skewed top byte: the shard is ordered by the top 16 bits of the mapped key (two stable passes);
+// bucket b's length = (index after its last key) - (index of its first).  Every boundary between neighbours of
+// different buckets adds its index to the bucket that ends there and subtracts it from the one that begins; the
+// slice's end adds n to the last bucket.  `counts` [65536] must be zero.
+template <typename K>
+__global__ __launch_bounds__(256) void top16_counts_kernel(const K* __restrict__ keys, uint64_t n, K neg, K pos, unsigned long long* __restrict__ counts) {
+    constexpr int W = sizeof(K) * 8;
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const uint32_t p = (uint32_t)(map_key<K>(keys[i], neg, pos) >> (W - 16));
+        if (i + 1 == n) {
+            atomicAdd(&counts[p], (unsigned long long)n);
+        } else {
+            const uint32_t q = (uint32_t)(map_key<K>(keys[i + 1], neg, pos) >> (W - 16));
+            if (p != q) {
+                atomicAdd(&counts[p], (unsigned long long)(i + 1));
+                atomicAdd(&counts[q], (unsigned long long)0 - (unsigned long long)(i + 1));
+            }
+        }
+    }
+}
+
 __global__ void raise_error_kernel(uint32_t* err, uint32_t bits) { atomicOr(err, bits); }  // rdst_hip_debug_raise_device_error
 
 // K6: one level's histogram + "digit sequence has an inversion" flag
@@ -2217,12 +2241,12 @@ KeyMap key_map_for(rdst_key_kind kind, uint32_t elem_bytes) {
 
 template <typename K, int LEVELS, int VEC, bool PAIR>
 int launch_hist_v(const K* keys, uint64_t n, uint32_t blocks, KeyMap km, unsigned long long* hpos, unsigned long long* hpair,
-                  uint32_t* inversion, const Plan* plan, hipStream_t s, uint64_t* piece_out) {
+                  uint32_t* inversion, const Plan* plan, hipStream_t s, uint64_t* piece_out, int base_level = 0) {
     *piece_out = hist_piece(n, blocks, (uint64_t)HIST_THREADS * VEC * 4);
     constexpr size_t lds = (size_t)HistPlan<LEVELS, PAIR>::WORDS * sizeof(uint32_t);
     if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&hist_kernel<K, LEVELS, VEC, PAIR>), lds)) return rc;
     hipLaunchKernelGGL((hist_kernel<K, LEVELS, VEC, PAIR>), dim3(blocks), dim3(HIST_THREADS), lds, s, keys, n, (K)km.neg,
-                       (K)km.pos, hpos, hpair, inversion, plan);
+                       (K)km.pos, hpos, hpair, inversion, plan, base_level);
     HIP_TRY(hipGetLastError());
     return RDST_OK;
 }
@@ -2230,7 +2254,7 @@ int launch_hist_v(const K* keys, uint64_t n, uint32_t blocks, KeyMap km, unsigne
 // pair == true also fills the joint tables the chain split of the later passes needs
 template <typename K, int LEVELS>
 int launch_hist(const K* keys, uint64_t n, uint32_t blocks, KeyMap km, unsigned long long* hpos, unsigned long long* hpair,
-                bool pair, uint32_t* inversion, const Plan* plan, hipStream_t s, uint64_t* piece_out) {
+                bool pair, uint32_t* inversion, const Plan* plan, hipStream_t s, uint64_t* piece_out, int base_level = 0) {
     const bool aligned = (reinterpret_cast<uintptr_t>(keys) & 15u) == 0;
     constexpr int V = 16 / sizeof(K);
     if constexpr (LEVELS >= 2) {
@@ -2239,8 +2263,8 @@ int launch_hist(const K* keys, uint64_t n, uint32_t blocks, KeyMap km, unsigned 
             return launch_hist_v<K, LEVELS, 1, true>(keys, n, blocks, km, hpos, hpair, inversion, plan, s, piece_out);
         }
     }
-    if (aligned) return launch_hist_v<K, LEVELS, V, false>(keys, n, blocks, km, hpos, hpair, inversion, plan, s, piece_out);
-    return launch_hist_v<K, LEVELS, 1, false>(keys, n, blocks, km, hpos, hpair, inversion, plan, s, piece_out);
+    if (aligned) return launch_hist_v<K, LEVELS, V, false>(keys, n, blocks, km, hpos, hpair, inversion, plan, s, piece_out, base_level);
+    return launch_hist_v<K, LEVELS, 1, false>(keys, n, blocks, km, hpos, hpair, inversion, plan, s, piece_out, base_level);
 }
 
 // K1h: the hybrid route's 65 536-bin count (same grid and pieces as K1)
@@ -2511,7 +2535,9 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
             if ((rc = prof_mark(*D, s, RDST_STAGE_ROUTE))) return rc;
         }
     }
-    rc = launch_hist<K, LEVELS>(keys, n, (uint32_t)blocks, km, hpos, hpair, pair, inversion, try_hybrid ? plan : nullptr, s, &piece);
+    // a single pass (the parity hook, the sharded route's split) counts its own level only: one LDS atomic per key
+    if (LEVELS > 1 && level_hi == level_lo + 1) rc = launch_hist<K, 1>(keys, n, (uint32_t)blocks, km, hpos, hpair, false, inversion, nullptr, s, &piece, (int)level_lo);
+    else rc = launch_hist<K, LEVELS>(keys, n, (uint32_t)blocks, km, hpos, hpair, pair, inversion, try_hybrid ? plan : nullptr, s, &piece);
     if (rc) return rc;
     if ((rc = prof_mark(*D, s, RDST_STAGE_HIST))) return rc;
     ScanArgs sa{};
@@ -2585,6 +2611,19 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     D->last_plan_valid = true;
     D->last_plan_off = L.off_plan;
     return workspace_release(*D, s);
+}
+
+template <typename K, int LV>
+int split_top16_t(void* dev_keys, void* dev_tmp, uint64_t len, rdst_key_kind kind, KeyMap km, uint32_t blocks, uint64_t* dev_counts16, hipStream_t s) {
+    if constexpr (LV >= 2) {
+        int rc = run_pipeline<K, LV>(static_cast<K*>(dev_keys), static_cast<K*>(dev_tmp), len, kind, LV - 2, LV, false, false, s, nullptr, nullptr);
+        if (rc) return rc;
+        hipLaunchKernelGGL((top16_counts_kernel<K>), dim3(blocks), dim3(256), 0, s, static_cast<const K*>(dev_keys), len, (K)km.neg, (K)km.pos,
+                           reinterpret_cast<unsigned long long*>(dev_counts16));
+        return RDST_OK;
+    } else {
+        return fail(RDST_ERR_UNSUPPORTED, "a 16-bit split needs keys of at least two bytes");
+    }
 }
 
 // run CALL with K = the unsigned integer type of `elem_bytes` bytes and LV = its RadixKey::LEVELS
@@ -3112,6 +3151,55 @@ int rdst_hip_scatter_level(const void* dev_src, void* dev_dst, uint64_t len, uin
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(s));
     return read_device_error(*D, s);
+}
+
+int rdst_hip_split_top_level_device(const void* dev_src, void* dev_dst, uint64_t len, uint32_t elem_bytes, rdst_key_kind kind,
+                                    uint64_t* dev_counts, void* stream) {
+    int rc = check_common(dev_src, len, elem_bytes, kind, elem_bytes);
+    if (rc) return rc;
+    if (!dev_counts) return fail(RDST_ERR_ARG, "null counts pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (len == 0) {
+        HIP_TRY(hipMemsetAsync(dev_counts, 0, sizeof(uint64_t) * RADIX, s));
+        return RDST_OK;
+    }
+    if (dev_dst == nullptr) return fail(RDST_ERR_ARG, "null dst pointer");
+    if (reinterpret_cast<uintptr_t>(dev_dst) % elem_bytes) return fail(RDST_ERR_ALIGN, "dst pointer not aligned to the element size");
+    std::lock_guard<std::mutex> lock(g_mutex);
+    Layout L;
+    char* ws = nullptr;
+    const uint32_t top = elem_bytes - 1;
+    // one un-skippable pass src -> dst on the top level; its K1 counts that level only; nothing blocks
+    RDST_BY_WIDTH(elem_bytes, rc = (run_pipeline<K, LV>(const_cast<K*>(static_cast<const K*>(dev_src)), static_cast<K*>(dev_dst), len, kind, top, top + 1, false, false, s, &L, &ws)));
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(dev_counts, ws + L.off_hist + sizeof(uint64_t) * (size_t)top * RADIX, sizeof(uint64_t) * RADIX, hipMemcpyDeviceToDevice, s));
+    DeviceState* D;
+    if ((rc = current_device_state(&D))) return rc;
+    return workspace_release(*D, s);  // the copy reads the workspace: later calls on other streams wait for it too
+}
+
+int rdst_hip_split_top16_device(void* dev_keys, void* dev_tmp, uint64_t len, uint32_t elem_bytes, rdst_key_kind kind,
+                                uint64_t* dev_counts16, void* stream) {
+    int rc = check_common(dev_keys, len, elem_bytes, kind, elem_bytes);
+    if (rc) return rc;
+    if (elem_bytes < 2) return fail(RDST_ERR_UNSUPPORTED, "a 16-bit split needs keys of at least two bytes");
+    if (!dev_counts16) return fail(RDST_ERR_ARG, "null counts pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemsetAsync(dev_counts16, 0, sizeof(uint64_t) * H16_BINS, s));
+    if (len == 0) return RDST_OK;
+    if (dev_tmp == nullptr) return fail(RDST_ERR_ARG, "null tmp pointer");
+    if (reinterpret_cast<uintptr_t>(dev_tmp) % elem_bytes) return fail(RDST_ERR_ALIGN, "tmp pointer not aligned to the element size");
+    std::lock_guard<std::mutex> lock(g_mutex);
+    DeviceState* D;
+    if ((rc = current_device_state(&D))) return rc;
+    const KeyMap km = key_map_for(kind, elem_bytes);
+    uint64_t blocks = (len + 255) / 256;
+    if (blocks > (uint64_t)D->cus * 16) blocks = (uint64_t)D->cus * 16;
+    // two stable passes on levels L-2, L-1 (keys -> tmp -> keys): the shard ends up ordered by its top 16 bits, in place
+    RDST_BY_WIDTH(elem_bytes, rc = (split_top16_t<K, LV>(dev_keys, dev_tmp, len, kind, km, (uint32_t)blocks, dev_counts16, s)));
+    if (rc) return rc;
+    HIP_TRY(hipGetLastError());
+    return RDST_OK;
 }
 
 int rdst_hip_level_counts(const void* dev_keys, uint64_t len, uint32_t elem_bytes, rdst_key_kind kind, uint32_t level,

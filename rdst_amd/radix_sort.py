@@ -240,8 +240,19 @@ class RadixSortBuilder:
         return d.size, key_info(d.dtype.name)[2]
 
     def sort(self):
+        """Sorts in place and returns None, like the reference — except when the tuner answers
+        ``Algorithm.GpuSharded``: the slice is then this rank's shard of a distributed array, the call is
+        collective over the default torch.distributed group (one rank per GPU), and the return value is a NEW
+        tensor, this rank's contiguous slice of the global order (its length differs from the input's, so it
+        cannot be written in place)."""
         n, levels = self._len_and_levels()
-        if n <= 1:  # radix_sort_builder.rs:151
+        algo = None
+        try:
+            import torch.distributed as dist
+            collective = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        except Exception:  # noqa: BLE001
+            collective = False
+        if n <= 1 and not collective:  # radix_sort_builder.rs:151 (a rank's shard of a distributed array may be empty)
             return
         if not isinstance(self._tuner, GpuTuner):
             if self._key:
@@ -253,7 +264,19 @@ class RadixSortBuilder:
             if algo not in (Algorithm.GpuLsd, Algorithm.GpuSharded):
                 raise NotImplementedError(
                     f"tuner picked {Algorithm(algo).name}: the CPU algorithms stay in the reference crate; "
-                    "this package implements the device route (Algorithm.GpuLsd) only")
+                    "this package implements the device routes (Algorithm.GpuLsd, Algorithm.GpuSharded) only")
+        if algo == Algorithm.GpuSharded:
+            import torch.distributed as dist
+            if not (dist.is_available() and dist.is_initialized()):
+                raise RuntimeError("Algorithm.GpuSharded is collective: it needs an initialised torch.distributed "
+                                   "process group with one rank per GPU (rdst_amd/sharded.py)")
+            if not _is_torch_tensor(self._data) or self._key:
+                raise NotImplementedError("Algorithm.GpuSharded sorts a HIP tensor of a dtype-described key type (this rank's shard)")
+            from .sharded import sharded_sort
+            out = sharded_sort(self._data)
+            if out.is_cuda:
+                device_status(out.device)
+            return out
         if _is_torch_tensor(self._data):
             if self._key == "bytes":
                 raise NotImplementedError("[u8; N] keys go through the host entry point: pass a numpy array")

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_functions():
     text = open(os.path.join(ROOT, "include", "rdst_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(rdst_[a-z_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(rdst_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_exports_every_declared_symbol(hiplib):

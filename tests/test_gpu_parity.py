@@ -397,6 +397,55 @@ def test_scatter_level_hook_is_the_reference_stable_pass(gpu, oracle, dtype):
         assert same_bits(to_host(t, dtype), a)  # source untouched
 
 
+def _heavy_digit_inputs(n, dtype, level, seed):
+    """inputs that put the lr variants of out_of_place_sort to work (src/sorts/out_of_place_sort.rs:202-389: a
+    bucket written from both ends when many equal digits sit next to each other) and the heavy-digit ranking of K3"""
+    rng = np.random.default_rng(seed)
+    w = np.dtype(dtype).itemsize * 8
+    ut = f"uint{w}"
+    base = random_bits(n, ut, seed).copy()
+    sh = np.array(8 * level, dtype=ut)
+    clear = ~(np.array(0xFF, dtype=ut) << sh)
+
+    def with_digits(d):
+        return ((base & clear) | (d.astype(ut) << sh)).view(dtype)
+
+    out = {}
+    d = rng.integers(0, 256, size=n)
+    d[rng.random(n) < 0.9] = 0x5A
+    out["90% one digit"] = with_digits(d)
+    out["two digits only"] = with_digits(rng.choice([3, 200], size=n))
+    out["one digit per 64-key round"] = with_digits(np.repeat(rng.integers(0, 256, size=(n + 63) // 64), 64)[:n])
+    out["sorted by digit"] = with_digits(np.sort(rng.integers(0, 256, size=n)))
+    out["long equal runs"] = with_digits(np.repeat(rng.integers(0, 256, size=(n + 999) // 1000), 1000)[:n])
+    return out
+
+
+@pytest.mark.parametrize("dtype", ("uint32", "int64", "float32"))
+def test_scatter_level_hook_on_heavy_digits_matches_every_oracle_variant(gpu, oracle, dtype):
+    """the reference's four out_of_place_sort variants (plain, with_counts, lr,
+    lr_with_counts) produce ONE result — each is a stable pass — and K3 must produce the same, also when one
+    digit crowds a wave (heavy-digit / single-digit-round ranking instead of the per-key LDS atomics).  The
+    next-level counts the *_with_counts variants return are checked against the all-levels hook (K1)."""
+    levels = np.dtype(dtype).itemsize
+    for n in (70_001, 1_200_007):
+        for level in (0, levels - 1):
+            for name, a in _heavy_digit_inputs(n, dtype, level, seed=n + level).items():
+                t = to_device(a)
+                dst, counts = gpu.scatter_level(t, level)
+                got = to_host(dst, dtype)
+                all_counts = gpu.all_level_counts(t)
+                for variant in ("plain", "with_counts", "lr", "lr_with_counts"):
+                    if variant.endswith("with_counts") and level + 1 >= levels:
+                        continue  # there is no next level to count (src/sorts/lsb_sort.rs:88-92 never asks for it)
+                    exp, next_counts = oracle.out_of_place_sort(a, level, variant)
+                    assert same_bits(got, exp), (dtype, n, level, name, variant)
+                    if next_counts is not None and level + 1 < levels:
+                        assert np.array_equal(next_counts, all_counts[level + 1]), (dtype, n, level, name, variant)
+                oc, _, _, _ = oracle.get_counts_with_ends(a, level)
+                assert np.array_equal(counts, oc), (dtype, n, level, name)
+
+
 def test_custom_tuner_round_trip(gpu):
     """with_tuner: pick_algorithm sees the top-level histogram of the slice (src/sorter.rs:67-76)."""
     from rdst_amd.tuner import Algorithm, StandardTuner, Tuner
