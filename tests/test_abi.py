@@ -52,7 +52,9 @@ def test_workspace_size_is_reported(hiplib):
     small = hiplib.rdst_hip_workspace_bytes(1000, 4)
     big = hiplib.rdst_hip_workspace_bytes(1_000_000_000, 4)
     assert 0 < small < big
-    assert big < 1_000_000_000  # status words are a small fraction of the key bytes (4 GB)
+    # status words (~0.5 GB) + the hybrid route's 16-bit halves array (2 bytes per key): well below the 4 GB of keys
+    assert big < 3_000_000_000
+    assert hiplib.rdst_hip_workspace_bytes(1_000_000_000, 8) < 2_000_000_000  # 8-byte keys: no halves array
     assert hiplib.rdst_hip_workspace_bytes(10, 3) == 0 and hiplib.rdst_hip_workspace_bytes(10, 16) > 0
 
 
