@@ -1859,6 +1859,162 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 8 : 6) void local_count_sort
     }
 }
 
+// K4 for 8-byte keys: the counting idea with a payload.  Inside a bucket 48 bits remain; the kernel orders the
+// bucket by bits [32, 48) with the counting sort of local_count_sort_kernel (same tables, same returning add) and
+// then puts the keys that tie on those 16 bits (uniform keys: one in nine, in groups of two or three; a group is
+// at most 15 by the counters' width) in order of their low 32 bits by counting, for each, the members of its
+// group that precede it — instead of six ranked passes.  Keys stay in registers throughout; LDS holds the
+// counters (32 KiB), the per-word prefixes (16 KiB) and the low halves at their slots (64 KiB), and that last
+// region then serves as the staging buffer for coalesced stores, half a tile at a time.  A counter that would
+// pass 15 sends the bucket to the generic kernel, untouched.
+constexpr int WIDE_THREADS = 1024;
+constexpr int WIDE_TILE = local_tile(8);   // 16 384
+constexpr size_t wide_lds_bytes() { return 32768 + 16384 + 4 * (size_t)WIDE_TILE + 128; }
+static_assert(WIDE_TILE % (2 * WIDE_THREADS) == 0, "two output halves of whole rounds");
+
+template <bool MAPPED>
+__global__ __launch_bounds__(WIDE_THREADS, 4) void local_wide_sort_kernel(
+    uint64_t* __restrict__ buf_keys, uint64_t* __restrict__ buf_tmp, const uint32_t* __restrict__ bstart, const Plan* __restrict__ plan,
+    uint32_t* __restrict__ err, uint64_t neg, uint64_t pos, uint32_t* __restrict__ list, uint32_t* __restrict__ list_count) {
+    constexpr int BLOCK = WIDE_THREADS, MAXR = WIDE_TILE / BLOCK, WPT = H16_BINS / BLOCK / 8, LOG_VPT = 6;
+    constexpr int HALF = WIDE_TILE / 2;
+    if (!plan->local_sort) return;
+    uint64_t* __restrict__ buf = plan->result_in_tmp ? buf_tmp : buf_keys;
+    const uint32_t bucket = blockIdx.x;
+    const uint32_t start = bstart[bucket], cnt = bstart[bucket + 1] - start;
+    if (cnt <= 1) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (cnt > (uint32_t)WIDE_TILE) {
+        if (tid == 0) atomicOr(err, ERR_LOCAL_OVERFLOW);
+        return;
+    }
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* cnt4 = reinterpret_cast<uint32_t*>(smem);                              // [WPT][BLOCK] eight 4-bit counters per word
+    uint16_t* prefix = reinterpret_cast<uint16_t*>(smem + 32768);                    // [WPT][BLOCK]
+    uint32_t* low32 = reinterpret_cast<uint32_t*>(smem + 32768 + 16384);             // [WIDE_TILE] low halves at their slots
+    uint64_t* out64 = reinterpret_cast<uint64_t*>(smem + 32768 + 16384);             // [HALF] output staging (same space, later)
+    uint32_t* s_wsum = reinterpret_cast<uint32_t*>(smem + 32768 + 16384 + 4 * WIDE_TILE);  // [16] wave sums, [16] overflow flag
+    __builtin_amdgcn_s_setprio(RDST_PRIO_LOAD);
+    const uint64_t* tsrc = buf + start;
+    uint64_t mk[MAXR];
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) {
+        const uint32_t idx = (uint32_t)tid + i * BLOCK;
+        mk[i] = tsrc[idx < cnt ? idx : cnt - 1];
+    }
+#pragma unroll
+    for (int k = 0; k < WPT; ++k) cnt4[k * BLOCK + tid] = 0;
+    if (tid == 0) s_wsum[16] = 0;
+    __syncthreads();
+    __builtin_amdgcn_s_setprio(0);
+    auto word_of = [](uint32_t v) -> uint32_t { return ((v >> 3) & (uint32_t)(WPT - 1)) * BLOCK + (v >> LOG_VPT); };
+    // Per-key state lives in the key's own top 16 bits (inside a bucket they are the bucket index, put back at the
+    // end): first the index among equal values, then the slot.  (A second register array for it made the compiler
+    // spill the keys themselves: 146 dwords of scratch per lane.)
+    constexpr uint64_t LOW48 = (1ull << 48) - 1;
+    bool over = false;
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) {
+        const uint32_t idx = (uint32_t)tid + i * BLOCK;
+        if (idx < cnt) {
+            if constexpr (MAPPED) mk[i] = map_key<uint64_t>(mk[i], neg, pos);
+            const uint32_t v = (uint32_t)(mk[i] >> 32) & 0xFFFFu;
+            const uint32_t sh = (v & 7u) * 4u;
+            const uint32_t old = atomicAdd(&cnt4[word_of(v)], 1u << sh);
+            const uint32_t mine = (old >> sh) & 15u;
+            over |= mine == 15u;
+            mk[i] = (mk[i] & LOW48) | ((uint64_t)mine << 48);
+        }
+    }
+    if (over) s_wsum[16] = 1;
+    __syncthreads();
+    if (s_wsum[16]) {  // block-uniform: the bucket stays as it is, for the generic kernel
+        if (tid == 0) list[atomicAdd(list_count, 1u)] = bucket;
+        return;
+    }
+    {
+        uint32_t pre[WPT];
+        uint32_t run = 0;
+#pragma unroll
+        for (int k = 0; k < WPT; ++k) {
+            pre[k] = run;
+            run = nibble_sum(cnt4[k * BLOCK + tid], run);
+        }
+        uint32_t incl = run;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(incl, o);
+            if (lane >= o) incl += y;
+        }
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        uint32_t base = incl - run;
+#pragma unroll
+        for (int x = 0; x < BLOCK / 64; ++x)
+            if (x < wave) base += s_wsum[x];
+#pragma unroll
+        for (int k = 0; k < WPT; ++k) prefix[k * BLOCK + tid] = (uint16_t)(base + pre[k]);
+    }
+    __syncthreads();
+    // slot by (value, index): the low half goes there, so that the members of a group can look at each other
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) {
+        const uint32_t idx = (uint32_t)tid + i * BLOCK;
+        if (idx < cnt) {
+            const uint32_t v = (uint32_t)(mk[i] >> 32) & 0xFFFFu, mine = (uint32_t)(mk[i] >> 48);
+            const uint32_t wd = word_of(v), sh = (v & 7u) * 4u;
+            const uint32_t slot = nibble_sum(cnt4[wd] & ((1u << sh) - 1u), (uint32_t)prefix[wd] + mine);
+            low32[slot] = (uint32_t)mk[i];
+            mk[i] = (mk[i] & LOW48) | ((uint64_t)slot << 48);
+        }
+    }
+    __syncthreads();
+    // ties: my place inside my group = members with a smaller low half (equal ones: by slot, so places stay distinct)
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) {
+        const uint32_t idx = (uint32_t)tid + i * BLOCK;
+        if (idx < cnt) {
+            const uint32_t v = (uint32_t)(mk[i] >> 32) & 0xFFFFu, slot = (uint32_t)(mk[i] >> 48);
+            const uint32_t wd = word_of(v), sh = (v & 7u) * 4u;
+            const uint32_t w = cnt4[wd];
+            const uint32_t group = (w >> sh) & 15u;
+            if (group >= 2u) {
+                const uint32_t first = nibble_sum(w & ((1u << sh) - 1u), (uint32_t)prefix[wd]);
+                const uint32_t lo = (uint32_t)mk[i];
+                uint32_t rank = 0;
+                for (uint32_t j = 0; j < group; ++j) {
+                    const uint32_t other = low32[first + j];
+                    rank += (other < lo || (other == lo && first + j < slot)) ? 1u : 0u;
+                }
+                mk[i] = (mk[i] & LOW48) | ((uint64_t)(first + rank) << 48);
+            }
+        }
+    }
+    __syncthreads();  // every look at the low halves is done: their space becomes the output staging
+    uint64_t* tdst = buf + start;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (h == 1 && cnt <= (uint32_t)HALF) break;  // block-uniform
+        __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i) {
+            const uint32_t idx = (uint32_t)tid + i * BLOCK;
+            const uint32_t rel = (uint32_t)(mk[i] >> 48) - (uint32_t)(h * HALF);
+            if (idx < cnt && rel < (uint32_t)HALF) out64[rel] = (mk[i] & LOW48) | ((uint64_t)bucket << 48);
+        }
+        __syncthreads();
+        __builtin_amdgcn_s_setprio(RDST_PRIO_SCATTER);
+#pragma unroll
+        for (int i = 0; i < HALF / BLOCK; ++i) {
+            const uint32_t rel = (uint32_t)tid + i * BLOCK, at = rel + (uint32_t)(h * HALF);
+            if (at < cnt) tdst[at] = MAPPED ? unmap_key<uint64_t>(out64[rel], neg, pos) : out64[rel];
+        }
+        if (h == 0) __syncthreads();  // the second half reuses the staging
+    }
+}
+
+
+
 // result sits in tmp after an odd number of executed passes: copy back
 // (src/sorts/lsb_sort.rs:117-126)
 template <typename K, int VEC>
@@ -2038,12 +2194,16 @@ constexpr PassCfg kPassCfgs[] = {
     {12, 24, 12, 2},  // 2: 768 threads, 18432 / 9216 keys per tile, two halves (36 KiB)   <- default, 4-byte keys from 4 GiB up, 16-byte keys
     {12, 28, 14, 2},  // 3: 768 threads, 21504 / 10752 keys per tile, two halves (42 KiB)  <- default, 8-byte keys
     {12, 22, 11, 1},  // 4: 768 threads, 16896 / 8448 keys per tile, whole tile staged (66 KiB; two blocks per CU only with 32-bit deltas)  <- default, keys up to 4 bytes below 4 GiB
+    {12, 20, 10, 1},  // 5: 768 threads, 15360 / 7680 keys per tile, whole tile staged (60 KiB: two blocks per CU with 64-bit deltas too)  <- default, signed / float 8-byte keys
 };
 constexpr int kNumPassCfgs = sizeof(kPassCfgs) / sizeof(kPassCfgs[0]);
 // 4-byte and narrower keys: the whole tile staged once (config 4) while two blocks still fit a CU,
 // i.e. while destinations are 32-bit offsets (n * size < 4 GiB); otherwise the two-stage shapes
-constexpr int default_cfg(uint32_t elem_bytes, uint64_t n) {
-    if (elem_bytes == 8) return 3;
+constexpr int default_cfg(uint32_t elem_bytes, uint64_t n, bool mapped = false) {
+    // 8-byte keys: unsigned ones run at copy speed either way (3.5 ms per 10^9-key pass against 3.4 for a copy of the
+    // same bytes); signed and float ones pay five more vector instructions per key use for the map, which the
+    // ballot ranking of the two-stage shape cannot hide (4.1-4.2 ms) and the returning-add ranking of shape 5 can (3.6)
+    if (elem_bytes == 8) return mapped ? 5 : 3;
     if (elem_bytes <= 4 && n * elem_bytes < (1ull << 32)) return 4;
     return 2;
 }
@@ -2314,8 +2474,23 @@ int launch_local_sort(K* keys, K* tmp, const uint32_t* bstart, const Plan* plan,
             HIP_TRY(hipGetLastError());
         }
     }
-    const dim3 grid(counting ? (uint32_t)(2 * cus) : (uint32_t)H16_BINS);
-    const uint32_t* wl = counting ? list : nullptr;
+    bool listed = counting;
+    if constexpr (sizeof(K) == 8) {
+        if (g_tuning.count_sort) {
+            constexpr size_t wlds = wide_lds_bytes();
+            if (mapped) {
+                if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_wide_sort_kernel<true>), wlds)) return rc;
+                hipLaunchKernelGGL((local_wide_sort_kernel<true>), dim3(H16_BINS), dim3(WIDE_THREADS), wlds, s, keys, tmp, bstart, plan, err, (uint64_t)km.neg, (uint64_t)km.pos, list, list_count);
+            } else {
+                if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_wide_sort_kernel<false>), wlds)) return rc;
+                hipLaunchKernelGGL((local_wide_sort_kernel<false>), dim3(H16_BINS), dim3(WIDE_THREADS), wlds, s, keys, tmp, bstart, plan, err, (uint64_t)km.neg, (uint64_t)km.pos, list, list_count);
+            }
+            HIP_TRY(hipGetLastError());
+            listed = true;
+        }
+    }
+    const dim3 grid(listed ? (uint32_t)((sizeof(K) == 8 ? 1 : 2) * cus) : (uint32_t)H16_BINS);
+    const uint32_t* wl = listed ? list : nullptr;
     if (mapped) {
         if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_sort_kernel<K, NW, KPT, true>), lds)) return rc;
         hipLaunchKernelGGL((local_sort_kernel<K, NW, KPT, true>), grid, dim3(NW * 64), lds, s, keys, tmp, bstart, plan, err, (K)km.neg, (K)km.pos, flags, wl, list_count, src16);
@@ -2364,6 +2539,7 @@ int launch_pass_s(int cfg, K* keys, K* tmp, uint64_t n, int level, const Layout&
         case 2: return launch_pass_t<K, S, kpt_for(12, sizeof(K)), 12, 2, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, cus, s);
         case 3: return launch_pass_t<K, S, kpt_for(14, sizeof(K)), 12, 2, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, cus, s);
         case 4: return launch_pass_t<K, S, kpt_for(11, sizeof(K)), 12, 1, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, cus, s);
+        case 5: return launch_pass_t<K, S, kpt_for(10, sizeof(K)), 12, 1, MAPPED, NARROW>(keys, tmp, n, level, L, ws, km, cus, s);
     }
     return fail(RDST_ERR_ARG, "pass config not built into this library (0 and 1 exist in the tools build only)");
 }
@@ -2447,7 +2623,7 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
         }
     }
     int cfg = g_tuning.pass_cfg;
-    if (cfg < 0 || cfg >= kNumPassCfgs) cfg = default_cfg(sizeof(K), n);
+    if (cfg < 0 || cfg >= kNumPassCfgs) cfg = default_cfg(sizeof(K), n, kind != RDST_KEY_UNSIGNED);
     // Hybrid route (whole sorts of 4- and 8-byte keys, long enough that a bucket is worth a workgroup, short
     // enough that 65 536 tiles can hold it): K1h counts the buckets, route_kernel decides.  If it says LSD,
     // K1 runs as ever (the slice is then read twice for counting); if it says hybrid, K1 returns at once.
@@ -2855,7 +3031,7 @@ int rdst_hip_profile_run_stages(int run, uint32_t* stages_out, uint32_t capacity
 uint64_t rdst_hip_workspace_bytes(uint64_t len, uint32_t elem_bytes) {
     if (elem_bytes != 1 && elem_bytes != 2 && elem_bytes != 4 && elem_bytes != 8 && elem_bytes != 16) return 0;
     int cfg = g_tuning.pass_cfg;
-    if (cfg < 0 || cfg >= kNumPassCfgs) cfg = default_cfg(elem_bytes, len);
+    if (cfg < 0 || cfg >= kNumPassCfgs) cfg = default_cfg(elem_bytes, len, true);  // the shape with the smaller tiles: an upper bound for every key kind
     const bool halves = elem_bytes == 4 && hybrid_eligible(len, 4) && g_tuning.halves && g_tuning.count_sort && cfg == 4 && len < (1ull << 30);
     return make_layout(len, elem_bytes, elem_bytes, cfg, 0, halves).total;
 }

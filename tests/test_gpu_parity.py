@@ -52,7 +52,8 @@ def test_host_entry_point_sorts_numpy_in_place(gpu, oracle):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_sort_matches_oracle_over_sizes(gpu, oracle, dtype):
-    tile = 16896 if np.dtype(dtype).itemsize == 4 else 10752  # default tile of the key width
+    # default tile of the key type: 4-byte keys 16 896, u64 10 752 (two-stage shape), i64 / f64 7 680 (whole-tile shape 5)
+    tile = 16896 if np.dtype(dtype).itemsize == 4 else (10752 if dtype == "uint64" else 7680)
     sizes = [0, 1, 2, 3, 10, 100, 127, 128, 129, 5_000, tile - 1, tile, tile + 1, 2 * tile - 1, 2 * tile + 1, 18432, 50_000,
              100_000, 8 * tile, 8 * tile + 31, 300_000, 1_000_003, 5_000_011]
     for i, n in enumerate(sizes):
@@ -93,14 +94,14 @@ def test_one_workgroup_sort_boundaries(gpu, dtype):
                     gpu.set_tuning()
 
 
-@pytest.mark.parametrize("dtype", ["uint32", "float32", "uint64", "uint16"])
+@pytest.mark.parametrize("dtype", ["uint32", "float32", "uint64", "float64", "uint16"])
 def test_every_built_pass_shape(gpu, dtype):
     """The scatter-kernel shapes the product library carries (two-stage 18 432 / 21 504-key tiles, whole-tile
-    16 896) each sort every key width, not only the one they are the default for."""
+    16 896 and 15 360) each sort every key width, not only the one they are the default for."""
     a = random_bits(1_500_007, dtype, seed=77).copy()
     exp = reference_sorted(a)
     try:
-        for cfg in (2, 3, 4):
+        for cfg in (2, 3, 4, 5):
             gpu.set_tuning(pass_config=cfg)
             assert same_bits(_device_sort(gpu, a), exp), (dtype, cfg)
     finally:
