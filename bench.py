@@ -356,7 +356,13 @@ def main():
                 e2e.append(time.perf_counter() - t0)
             if gpu_sorted_host is not None:
                 assert np.array_equal(h.view(f"u{kb}"), gpu_sorted_host.view(f"u{kb}")), "host entry point and device path differ"
+            import ctypes
+            from rdst_amd import _lib
+            t3 = [ctypes.c_float(0) for _ in range(3)]
+            _lib.check(_lib.load().rdst_hip_host_timing(*[ctypes.byref(x) for x in t3]))
             line["end_to_end"] = {"ms": round(min(e2e) * 1e3, 2), "Gkeys_per_s": round(n / min(e2e) / 1e9, 3),
+                                  "last_call_breakdown_ms": {"h2d": round(t3[0].value, 2), "sort_and_status": round(t3[1].value, 2), "d2h": round(t3[2].value, 2)},
+                                  "link_GBps": {"h2d": round(kb * n / (t3[0].value * 1e-3) / 1e9, 1), "d2h": round(kb * n / (t3[2].value * 1e-3) / 1e9, 1)},
                                   "what": "rdst_hip_sort on a host numpy slice of the same keys: H2D + sort + D2H, best of 2 (never `value`)"}
             del h
         del src

@@ -120,6 +120,12 @@ typedef struct {
 int rdst_hip_sort(void* host_data, uint64_t len, uint32_t elem_bytes, rdst_key_kind kind,
                   uint32_t levels, const rdst_hip_opts* opts);
 
+/* Where the time of the most recent rdst_hip_sort on the current device went (HIP events on its stream): the copy
+ * to the device, the device sort (incl. its status check), the copy back.  10^9 u32 keys: 2 x 4 GB at the link's
+ * ~51 GB/s and 6 ms of sorting; a sort needs its whole input before its first output, so the two copies cannot
+ * overlap each other. */
+int rdst_hip_host_timing(float* h2d_ms, float* sort_ms, float* d2h_ms);
+
 /* Device-resident form of the same call — the timed path.  `dev_keys` holds the keys and
  * receives the sorted result; `dev_tmp` is a caller-provided scratch of the same size
  * (the `tmp_bucket` of src/sorts/lsb_sort.rs:53).  Asynchronous on `stream`.  The LSD

@@ -18,6 +18,7 @@ RDST_OK = 0
 SYMBOLS = (
     "rdst_hip_sort",
     "rdst_hip_sort_device",
+    "rdst_hip_host_timing",
     "rdst_hip_sort_pairs_device",
     "rdst_hip_sort_records",
     "rdst_hip_device_status",
@@ -86,6 +87,7 @@ def load():
     vp, u64, u32, ci = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int
     u64p, u8p = ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint8)
     lib.rdst_hip_sort.argtypes = [vp, u64, u32, ci, u32, ctypes.POINTER(HipOptsC)]
+    lib.rdst_hip_host_timing.argtypes = [ctypes.POINTER(ctypes.c_float)] * 3
     lib.rdst_hip_sort_device.argtypes = [vp, vp, u64, u32, ci, u32, vp]
     lib.rdst_hip_sort_pairs_device.argtypes = [vp, vp, vp, vp, u64, u32, ci, u32, u32, vp]
     lib.rdst_hip_sort_records.argtypes = [vp, u64, u32, u32, u32, ci, ctypes.POINTER(HipOptsC)]

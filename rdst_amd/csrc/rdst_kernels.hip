@@ -2243,6 +2243,8 @@ struct DeviceState {
     void* host_buf = nullptr;           // their device buffer (keys + tmp), kept and grown on demand
     size_t host_buf_bytes = 0;
     std::mutex host_mutex;              // one host-slice sort per device at a time (they share stream and buffer)
+    hipEvent_t host_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // around H2D, sort, D2H of the most recent host-slice sort
+    bool host_timed = false;
     hipEvent_t last_done = nullptr;  // recorded after every enqueue that uses the workspace
     hipStream_t last_stream = nullptr;
     bool have_last = false;
@@ -3189,7 +3191,12 @@ int rdst_hip_sort(void* host_data, uint64_t len, uint32_t elem_bytes, rdst_key_k
     void* d_keys = use_pool ? pool_buf : D->host_buf;
     void* d_tmp = static_cast<char*>(d_keys) + half;
     struct PoolGuard { void* p; hipStream_t s; ~PoolGuard() { if (p) (void)hipFreeAsync(p, s); } } pool_guard{pool_nofree ? nullptr : pool_buf, s};
+    D->host_timed = false;
+    for (auto& ev : D->host_ev)
+        if (!ev && (e = hipEventCreate(&ev)) != hipSuccess) return done(fail(RDST_ERR_HIP, "hipEventCreate", e));
+    (void)hipEventRecord(D->host_ev[0], s);
     if ((e = hipMemcpyAsync(d_keys, host_data, bytes, hipMemcpyHostToDevice, s)) != hipSuccess) { (void)hipStreamSynchronize(s); return done(fail(RDST_ERR_HIP, "H2D", e)); }
+    (void)hipEventRecord(D->host_ev[1], s);
     if (pool_sync) (void)hipStreamSynchronize(s);
     if (host_debug) {
         fprintf(stderr, "[host] len=%llu elem=%u keys=[%p,%p) tmp=[%p,%p) ws=[%p,%p)\n", (unsigned long long)len, elem_bytes, d_keys,
@@ -3205,14 +3212,34 @@ int rdst_hip_sort(void* host_data, uint64_t len, uint32_t elem_bytes, rdst_key_k
     if (rc == RDST_OK) rc = rdst_hip_device_status(s);
     if (rc != RDST_OK) { (void)hipStreamSynchronize(s); return done(rc); }
     // the host buffer is written only now, after the device reported success
+    (void)hipEventRecord(D->host_ev[2], s);
     if ((e = hipMemcpyAsync(host_data, d_keys, bytes, hipMemcpyDeviceToHost, s)) != hipSuccess) { (void)hipStreamSynchronize(s); return done(fail(RDST_ERR_HIP, "D2H", e)); }
+    (void)hipEventRecord(D->host_ev[3], s);
     if ((e = hipStreamSynchronize(s)) != hipSuccess) return done(fail(RDST_ERR_HIP, "sync", e));
+    D->host_timed = true;
     if (D->host_buf_bytes > ((size_t)1 << 30)) {  // do not sit on gigabytes between calls
         (void)hipFree(D->host_buf);
         D->host_buf = nullptr;
         D->host_buf_bytes = 0;
     }
     return done(RDST_OK);
+}
+
+int rdst_hip_host_timing(float* h2d_ms, float* sort_ms, float* d2h_ms) {
+    DeviceState* D = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_mutex);
+        int rc = current_device_state(&D);
+        if (rc) return rc;
+    }
+    std::lock_guard<std::mutex> host_lock(D->host_mutex);
+    if (!D->host_timed) return fail(RDST_ERR_ARG, "no host-slice sort has completed on this device yet");
+    float t[3] = {0, 0, 0};
+    for (int i = 0; i < 3; ++i) HIP_TRY(hipEventElapsedTime(&t[i], D->host_ev[i], D->host_ev[i + 1]));
+    if (h2d_ms) *h2d_ms = t[0];
+    if (sort_ms) *sort_ms = t[1];
+    if (d2h_ms) *d2h_ms = t[2];
+    return RDST_OK;
 }
 
 int rdst_hip_sort_records(void* host_records, uint64_t len, uint32_t record_bytes, uint32_t key_offset, uint32_t key_bytes,

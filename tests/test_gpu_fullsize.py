@@ -33,16 +33,24 @@ def _is_sorted(torch, m, chunk=1 << 27):
     return True
 
 
-@pytest.mark.parametrize("name,itype_name,seed", [("uint32", "int32", 0x5D570002), ("uint64", "int64", 0x5D570003),
-                                                   ("float32", "int32", 0x5D570004)])
-def test_one_billion_keys(gpu, name, itype_name, seed):
+@pytest.mark.parametrize("name,itype_name,seed,route", [("uint32", "int32", 0x5D570002, "hybrid"), ("uint32", "int32", 0x5D570002, "lsd"),
+                                                         ("uint64", "int64", 0x5D570003, "hybrid"), ("float32", "int32", 0x5D570004, "hybrid"),
+                                                         ("float64", "int64", 0x5D570007, "hybrid")])
+def test_one_billion_keys(gpu, name, itype_name, seed, route):
+    """`route`: uniform 10^9-key slices take the hybrid route by the device's own choice (asserted); the LSD route
+    — every skewed input's route — is forced once at full size too."""
     import torch
     itype = getattr(torch, itype_name)
     src = _gen(torch, N, itype, seed)
     keys = src.clone()
     view = keys.view(getattr(torch, name))
     before = gpu.all_level_counts(view)
-    gpu.sort_device_tensor(view)
+    gpu.set_hybrid(route == "hybrid")
+    try:
+        gpu.sort_device_tensor(view)
+        assert gpu.last_route() == route
+    finally:
+        gpu.set_hybrid(True)
     after = gpu.all_level_counts(view)
     assert np.array_equal(before, after)                       # same multiset, digit by digit
     assert int(keys.sum()) == int(src.sum())                   # wrapping checksum
@@ -51,7 +59,7 @@ def test_one_billion_keys(gpu, name, itype_name, seed):
     assert _is_sorted(torch, m)
     del m
     once = keys.clone()
-    gpu.sort_device_tensor(view)                                # idempotence (all levels "already sorted")
+    gpu.sort_device_tensor(view)                                # idempotence (no inversion: no pass, no local sort)
     assert bool((keys == once).all())
     del once, src
     # a slice small enough for the oracle-free numpy check, bit-exact against an independent sort
