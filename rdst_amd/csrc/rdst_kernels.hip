@@ -98,6 +98,8 @@ struct Plan {
     uint32_t first_level;             // lowest executed level: below it nothing has ordered the keys (order test of K3's fast ranking)
     uint32_t route;                   // ROUTE_LSD or ROUTE_HYBRID (decided on the device by route_kernel)
     uint32_t local_sort;              // hybrid route and the slice is not already sorted: K4 runs
+    uint32_t gross_skew;              // a sample of the keys already rules the hybrid route out (presample_kernel): K1h returns at once
+    uint32_t sorted_known;            // K1h swept the whole slice and met no inversion: K1 need not read it again (K2 turns every pass off)
 };
 
 // Look-back chains.  One chain over all tiles makes every tile walk back over ~(status latency /
@@ -257,7 +259,7 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const K* __restrict_
                                                             const Plan* __restrict__ plan /* nullable: the hybrid route has its own counts (K1h) */,
                                                             int base_level /* table row and digit of this kernel's level 0 (one-level counts of a single pass: LEVELS == 1) */) {
     using P = HistPlan<LEVELS, PAIR>;
-    if (plan && plan->route == ROUTE_HYBRID) return;
+    if (plan && (plan->route == ROUTE_HYBRID || plan->sorted_known)) return;  // (sorted: K2 turns every pass off whatever the counts)
     constexpr int COPIES = P::COPIES, PCOPIES = P::PCOPIES, WORDS = P::WORDS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* s_h = reinterpret_cast<uint32_t*>(smem);
@@ -389,6 +391,50 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const K* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------
+// A look before K1h.  An input the hybrid route cannot take (some 16-bit prefix holding more than a tile) would
+// otherwise pay K1h's full read (0.8 ms per 10^9 u32 keys) before falling back to the LSD route.  One block counts
+// the prefixes of 65 536 keys at evenly spaced positions (8-bit counters, 64 KiB of LDS): the largest bucket the
+// route accepts expects about one hit, so PRESAMPLE_LIMIT hits on one prefix cannot happen by chance
+// (Poisson(1.1) >= 12: 1e-9 per bucket) and mean a bucket thousands of times over the bound; K1h then returns at
+// once and the sort goes the LSD way.  Milder skew is not seen here and is caught by K1h's exact counts as before.
+// Cost: ~10 us per hybrid-eligible sort (one batch of eight loads per thread).
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t PRESAMPLE_KEYS = 8192;  // 65 536 spread-out keys cost 0.17 ms (a TLB miss each); 8 192 in one batch of loads: ~0.01 ms
+constexpr uint64_t PRESAMPLE_MIN_LEN = 1ull << 28;  // below it a full tile expects more hits than 8-bit counters and a small limit allow
+constexpr size_t presample_lds_bytes() { return H16_BINS + 16; }
+
+template <typename K, bool MAPPED>
+__global__ __launch_bounds__(1024) void presample_kernel(const K* __restrict__ keys, uint64_t n, K neg, K pos, Plan* __restrict__ plan, uint32_t limit) {
+    constexpr int W = sizeof(K) * 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* s_c = reinterpret_cast<uint32_t*>(smem);               // 65 536 8-bit counters, four per word
+    uint32_t* s_skew = reinterpret_cast<uint32_t*>(smem + H16_BINS);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < H16_BINS / 4; i += 1024) s_c[i] = 0;
+    if (tid == 0) *s_skew = 0;
+    __syncthreads();
+    const uint64_t step = n / PRESAMPLE_KEYS;
+    bool skew = false;
+    static_assert(PRESAMPLE_KEYS == 8 * 1024, "eight keys per thread, one batch");
+    K v[8];
+    {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = keys[((uint64_t)u * 1024 + tid) * step];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const K m = MAPPED ? map_key<K>(v[u], neg, pos) : v[u];
+            const uint32_t b = (uint32_t)(m >> (W - 16));
+            const uint32_t sh = (b & 3u) * 8u;
+            const uint32_t old = atomicAdd(&s_c[b >> 2], 1u << sh);
+            skew |= ((old >> sh) & 0xFFu) + 1u >= limit;  // limit <= 64: the flag fires long before a counter could carry
+        }
+    }
+    if (skew) *s_skew = 1;
+    __syncthreads();
+    if (tid == 0 && *s_skew) plan->gross_skew = 1;
+}
+
+// ------------------------------------------------------------------------------------------
 // K1h: histogram of the TOP 16 BITS of the mapped key (65 536 buckets) from one read — what the
 // hybrid route needs: bucket sizes (does every bucket fit K4's tile?), bucket starts, and, summed
 // the right way, everything K2 wants for the two K3 passes on levels L-2 and L-1 (digit totals,
@@ -411,8 +457,10 @@ template <typename K, int VEC, bool MAPPED>
 __global__ __launch_bounds__(HIST_THREADS) void hist16_kernel(const K* __restrict__ keys, uint64_t n, K neg, K pos,
                                                               uint32_t* __restrict__ h16 /* [65536] bucket counts */,
                                                               unsigned long long* __restrict__ hpos16 /* [CHAINS][256]: digit L-2 per position range */,
-                                                              uint32_t* __restrict__ inversion, uint32_t* __restrict__ overflow) {
+                                                              uint32_t* __restrict__ inversion, uint32_t* __restrict__ overflow,
+                                                              const Plan* __restrict__ plan) {
     constexpr int W = sizeof(K) * 8;
+    if (plan->gross_skew) return;  // the sample ruled the hybrid route out: K1 will count (and look for inversions) instead
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* s_h = reinterpret_cast<uint32_t*>(smem);
     __shared__ unsigned long long s_sum;
@@ -545,12 +593,13 @@ struct RouteArgs {
     const uint32_t* h16;              // [65536]
     const unsigned long long* hpos16; // [CHAINS][256]
     const uint32_t* overflow;
+    const uint32_t* inversion;        // K1h's "some key is smaller than its predecessor"
     uint32_t* bstart;                 // [65537] out
     unsigned long long* hpos;         // [levels][CHAINS][256] (zeroed)
     unsigned long long* hpair;        // [levels][CHAINS][256] (zeroed)
     Plan* plan;
     uint64_t n;
-    uint32_t levels, cap;
+    uint32_t levels, cap, allow_skip;
 };
 
 __global__ __launch_bounds__(1024) void route_kernel(RouteArgs a) {
@@ -585,8 +634,11 @@ __global__ __launch_bounds__(1024) void route_kernel(RouteArgs a) {
         if (w < wave) excl += s_wsum[w];
         bmax = s_wmax[w] > bmax ? s_wmax[w] : bmax;
     }
-    const bool hybrid = *a.overflow == 0 && bmax <= a.cap;
-    if (tid == 0) a.plan->route = hybrid ? ROUTE_HYBRID : ROUTE_LSD;
+    const bool hybrid = *a.overflow == 0 && bmax <= a.cap && a.plan->gross_skew == 0;  // (K1h returned at once then: its counts are all zero)
+    if (tid == 0) {
+        a.plan->route = hybrid ? ROUTE_HYBRID : ROUTE_LSD;
+        a.plan->sorted_known = (a.plan->gross_skew == 0 && *a.inversion == 0 && a.allow_skip) ? 1u : 0u;
+    }
     if (!hybrid) return;
     uint32_t run = excl;
     uint4* dst = reinterpret_cast<uint4*>(a.bstart) + (size_t)tid * 16;
@@ -2220,6 +2272,7 @@ struct Tuning {
     bool hybrid = true;                 // consider the hybrid route at all
     bool count_sort = true;             // 4-byte keys: K4 as a counting sort by value (false: the generic ranked passes)
     bool halves = true;                 // 4-byte keys: pass L-1 hands K4 the low halves only (16-bit array in the workspace)
+    bool presample = true;              // a 65 536-key sample before K1h: gross skew goes straight to the LSD route
     uint64_t hybrid_min_len = 1ull << 28;  // below this the buckets are too small for one workgroup each to pay off
 };
 uint32_t g_ablate = 0;  // only ever set by the RDST_EXPERIMENTS build
@@ -2432,16 +2485,28 @@ int launch_hist(const K* keys, uint64_t n, uint32_t blocks, KeyMap km, unsigned 
 // K1h: the hybrid route's 65 536-bin count (same grid and pieces as K1)
 template <typename K>
 int launch_hist16(const K* keys, uint64_t n, uint32_t blocks, KeyMap km, uint32_t* h16, unsigned long long* hpos16, uint32_t* inversion,
-                  uint32_t* overflow, hipStream_t s) {
+                  uint32_t* overflow, Plan* plan, hipStream_t s) {
     const bool aligned = (reinterpret_cast<uintptr_t>(keys) & 15u) == 0;
     const bool mapped = km.neg != 0 || km.pos != 0;
+    if (g_tuning.presample && n >= PRESAMPLE_MIN_LEN) {
+        const uint32_t limit = 12u + (uint32_t)(4ull * (uint64_t)local_tile(sizeof(K)) * PRESAMPLE_KEYS / n);
+        constexpr size_t plds = presample_lds_bytes();
+        if (mapped) {
+            if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&presample_kernel<K, true>), plds)) return rc;
+            hipLaunchKernelGGL((presample_kernel<K, true>), dim3(1), dim3(1024), plds, s, keys, n, (K)km.neg, (K)km.pos, plan, limit);
+        } else {
+            if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&presample_kernel<K, false>), plds)) return rc;
+            hipLaunchKernelGGL((presample_kernel<K, false>), dim3(1), dim3(1024), plds, s, keys, n, (K)km.neg, (K)km.pos, plan, limit);
+        }
+        HIP_TRY(hipGetLastError());
+    }
     constexpr int V = 16 / sizeof(K);
     constexpr size_t lds = (size_t)H16_WORDS * sizeof(uint32_t);
 #define RDST_H16(VEC, MAPPED)                                                                                              \
     do {                                                                                                                   \
         if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&hist16_kernel<K, VEC, MAPPED>), lds)) return rc;       \
         hipLaunchKernelGGL((hist16_kernel<K, VEC, MAPPED>), dim3(blocks), dim3(HIST_THREADS), lds, s, keys, n, (K)km.neg,  \
-                           (K)km.pos, h16, hpos16, inversion, overflow);                                                   \
+                           (K)km.pos, h16, hpos16, inversion, overflow, plan);                                             \
     } while (0)
     if (aligned) { if (mapped) RDST_H16(V, true); else RDST_H16(V, false); }
     else { if (mapped) RDST_H16(1, true); else RDST_H16(1, false); }
@@ -2691,13 +2756,15 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
             uint32_t* overflow = reinterpret_cast<uint32_t*>(ws + L.off_err) + 2;
             uint32_t* h16 = reinterpret_cast<uint32_t*>(ws + L.off_h16);
             unsigned long long* hpos16 = reinterpret_cast<unsigned long long*>(ws + L.off_hpos16);
-            rc = launch_hist16<K>(keys, n, (uint32_t)blocks, km, h16, hpos16, inversion, overflow, s);
+            rc = launch_hist16<K>(keys, n, (uint32_t)blocks, km, h16, hpos16, inversion, overflow, plan, s);
             if (rc) return rc;
             if ((rc = prof_mark(*D, s, RDST_STAGE_HIST16))) return rc;
             RouteArgs ra{};
             ra.h16 = h16;
             ra.hpos16 = hpos16;
             ra.overflow = overflow;
+            ra.inversion = inversion;
+            ra.allow_skip = allow_skip ? 1u : 0u;
             ra.bstart = reinterpret_cast<uint32_t*>(ws + L.off_bstart);
             ra.hpos = hpos;
             ra.hpair = hpair;
@@ -2881,6 +2948,7 @@ int rdst_hip_set_hybrid(int enabled, uint64_t min_len) {
     g_tuning.hybrid = enabled != 0;
     g_tuning.count_sort = enabled != 2;  // 2: hybrid route with the generic local sort for every key width (A/B, tests)
     g_tuning.halves = enabled != 3;      // 3: counting K4 reading whole keys (no 16-bit hand-off) (A/B, tests)
+    g_tuning.presample = enabled != 5;   // 5: no sample before K1h: every hybrid-eligible sort counts all its keys' prefixes first (tests)
     g_tuning.hybrid_min_len = min_len ? min_len : (1ull << 28);
     return RDST_OK;
 }

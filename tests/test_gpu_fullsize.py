@@ -94,3 +94,27 @@ def test_more_than_2_pow_30_keys_uses_wide_status_words(gpu):
     gpu.sort_device_tensor(keys.view(torch.uint32))
     assert int(keys.sum()) == int(src.sum())
     assert _is_sorted(torch, keys ^ torch.iinfo(torch.int32).min)
+
+
+def test_skewed_full_size_inputs_take_the_lsd_route_and_gross_skew_skips_k1h(gpu):
+    """The reference's bimodal bench input (gen_inputs with shift 16, src/test_utils.rs:51-61 / benches/full_sort.rs:68-78) at
+    5·10^8 keys: half the keys share the 16-bit prefix 0 — the 65 536-key sample before K1h sees it and K1h returns at once;
+    an input with ONE bucket one key over the tile is invisible to the sample and must be caught by K1h's exact counts."""
+    import torch
+    n = 500_000_000
+    src = _gen(torch, n, torch.int32, 0x5D570008)
+    bimodal = torch.cat([(src[: n // 2] >> 16) & 0xFFFF, src[n // 2:] << 16])
+    borderline = src.clone()
+    borderline[:16_897] = (borderline[:16_897] & 0xFFFF) | (0x1234 << 16)   # >= 16 897 keys with prefix 0x1234 (+ ~7 600 random ones)
+    for name, inp, k1h_runs in (("bimodal", bimodal, False), ("borderline", borderline, True)):
+        keys = inp.clone()
+        gpu.sort_device_tensor(keys.view(torch.uint32))   # first use of a kernel loads its code object: not timed
+        keys.copy_(inp)
+        gpu.set_profiling(True)
+        gpu.sort_device_tensor(keys.view(torch.uint32))
+        prof = gpu.profile_run(-1, 4)
+        gpu.set_profiling(False)
+        assert gpu.last_route() == "lsd", name
+        assert (prof["histogram16"] > 0.2) == k1h_runs, (name, prof["histogram16"])   # 0.4 ms when it reads the slice, microseconds when it returns
+        assert int(keys.sum()) == int(inp.sum())
+        assert _is_sorted(torch, keys ^ torch.iinfo(torch.int32).min), name

@@ -185,6 +185,25 @@ def test_already_sorted_input_runs_no_pass_on_either_route(hybrid):
     assert same_bits(to_host(t, a.dtype), a)
 
 
+def test_k1h_sees_every_adjacent_pair(hybrid):
+    """The already-sorted exit now also rests on K1h's inversion test (a sorted slice makes K1 return at once): one
+    swapped pair anywhere — inside a lane's vector, between lanes, between waves, between blocks' pieces, at the ends —
+    must be seen, or the slice would come back unsorted."""
+    n = 3_000_000
+    base = np.sort(random_bits(n, "uint32", seed=77))
+    base = np.unique(base)          # strictly increasing: every swap is an inversion
+    n = base.size
+    piece = -(-n // 256)            # K1h's pieces are multiples of 16 384 keys; probe around plausible boundaries anyway
+    spots = [0, 1, 2, 3, 4, 63, 64, 255, 256, 4095, 4096, 16383, 16384, 16385, piece - 1, piece, 2 * piece, n // 2, n - 3, n - 2]
+    for i in spots:
+        a = base.copy()
+        a[i], a[i + 1] = a[i + 1], a[i]
+        got, _ = _sort(hybrid, a)
+        assert same_bits(got, base), i
+    got, _ = _sort(hybrid, base.copy())
+    assert same_bits(got, base)
+
+
 def test_device_error_word_is_sticky_until_checked(gpu):
     """An error raised by an earlier asynchronous sort must still be reported after later sorts were
     enqueued: the word lives outside the per-sort workspace; the check reports it once."""
