@@ -217,6 +217,38 @@ int rdst_hip_split_top_level_device(const void* dev_src, void* dev_dst, uint64_t
 int rdst_hip_split_top16_device(void* dev_keys, void* dev_tmp, uint64_t len, uint32_t elem_bytes,
                                 rdst_key_kind kind, uint64_t* dev_counts16, void* stream);
 
+/* ---- low-memory route ------------------------------------------------------------------------
+ * Device twin of the route `with_low_mem_tuner()` selects (src/radix_sort_builder.rs:74-77; LowMemoryTuner picks Regions
+ * above 10^6 elements, Ska below: src/tuners/low_memory_tuner.rs:36-41): sorts `dev_keys` IN PLACE with a scratch of
+ * only `tmp_len` elements (`dev_tmp`; len / 64 is a good size, anything from 2^16 elements up works) instead of a second
+ * array.  One Regions-sort level (src/sorts/regions_sort.rs:51-286) on the most significant unsorted digit: every tile of
+ * tmp_len keys is grouped by digit through the scratch (the per-tile ska_sort of :216-223), the tile x digit counts
+ * come to the host, which plans equal-length block swaps in rounds (the reference plans them serially too, :235-239) and
+ * a swap kernel runs them; then groups of buckets that fit the scratch are sorted by the ordinary device route, and a
+ * bucket that does not fit takes another Regions level on the next digit.  BLOCKING (the plan is made on the host).
+ * Same result as rdst_hip_sort_device, bit for bit. */
+int rdst_hip_sort_device_lowmem(void* dev_keys, uint64_t len, uint32_t elem_bytes, rdst_key_kind kind, uint32_t levels,
+                                void* dev_tmp, uint64_t tmp_len, void* stream);
+
+/* `partition_index` (src/sort_utils.rs:295-331: two-ended in-place partition by a predicate; Ska, Scanning and Regions
+ * use it to move the largest bucket aside first) as a device operation: keys whose digit `level` equals `digit` first,
+ * the others after, in place, with the same scratch and swap machinery (a two-country Regions level).  Returns the split
+ * index in *split_out.  The order inside the two parts is unspecified, as in the reference.  BLOCKING. */
+int rdst_hip_partition_device(void* dev_keys, uint64_t len, uint32_t elem_bytes, rdst_key_kind kind, uint32_t level,
+                              uint32_t digit, void* dev_tmp, uint64_t tmp_len, uint64_t* split_out, void* stream);
+
+/* The swap plan of one Regions level, host only (what rdst_hip_sort_device_lowmem runs; exposed so that it can be
+ * checked without a device).  Every tile consists of `columns` runs, in order; tile_counts[t * columns + c] = length of
+ * run c of tile t, col_bucket[c] = the bucket its keys belong to (NULL: column c is bucket c, columns == buckets);
+ * tiles = ceil(len / tile_len).  ops_out[round_starts[r] .. round_starts[r + 1]) are the swaps of round r: exchange
+ * `len` elements at `a` with those at `b`; the ranges of one round are pairwise disjoint.  starts_out (nullable,
+ * buckets + 1 entries) receives the region borders. */
+typedef struct { uint64_t a, b, len; } rdst_swap_op;
+int rdst_regions_plan(const uint64_t* tile_counts, uint64_t tiles, uint64_t tile_len, uint64_t len, uint32_t columns,
+                      const uint32_t* col_bucket, uint32_t buckets, rdst_swap_op* ops_out, uint64_t ops_capacity,
+                      uint64_t* nops_out, uint64_t* round_starts, uint32_t max_rounds, uint32_t* nrounds_out,
+                      uint64_t* starts_out);
+
 /* Replaces `Tuner::pick_algorithm` (src/tuner.rs:33-35) for the stock tuners: pure
  * integer decision tables, host only.  counts has 256 entries (src/sorter.rs:67-76).
  * gpu_min_len is read only by RDST_TUNER_GPU.  For host slices the device route starts to win at

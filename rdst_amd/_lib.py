@@ -18,6 +18,9 @@ RDST_OK = 0
 SYMBOLS = (
     "rdst_hip_sort",
     "rdst_hip_sort_device",
+    "rdst_hip_sort_device_lowmem",
+    "rdst_hip_partition_device",
+    "rdst_regions_plan",
     "rdst_hip_host_timing",
     "rdst_hip_sort_pairs_device",
     "rdst_hip_sort_records",
@@ -88,6 +91,8 @@ def load():
     u64p, u8p = ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint8)
     lib.rdst_hip_sort.argtypes = [vp, u64, u32, ci, u32, ctypes.POINTER(HipOptsC)]
     lib.rdst_hip_host_timing.argtypes = [ctypes.POINTER(ctypes.c_float)] * 3
+    lib.rdst_hip_sort_device_lowmem.argtypes = [vp, u64, u32, ci, u32, vp, u64, vp]
+    lib.rdst_hip_partition_device.argtypes = [vp, u64, u32, ci, u32, u32, vp, u64, u64p, vp]
     lib.rdst_hip_sort_device.argtypes = [vp, vp, u64, u32, ci, u32, vp]
     lib.rdst_hip_sort_pairs_device.argtypes = [vp, vp, vp, vp, u64, u32, ci, u32, u32, vp]
     lib.rdst_hip_sort_records.argtypes = [vp, u64, u32, u32, u32, ci, ctypes.POINTER(HipOptsC)]

@@ -6,7 +6,8 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SOURCES = [os.path.join(HERE, "csrc", "rdst_kernels.hip"), os.path.join(HERE, "csrc", "rdst_tuner.cpp")]
+SOURCES = [os.path.join(HERE, "csrc", "rdst_kernels.hip"), os.path.join(HERE, "csrc", "rdst_tuner.cpp"),
+           os.path.join(HERE, "csrc", "rdst_regions.cpp")]
 HEADERS = [os.path.join(ROOT, "include", "rdst_hip.h")]
 OUT = os.path.join(HERE, "librdst_hip.so")
 

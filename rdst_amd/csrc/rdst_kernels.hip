@@ -2190,6 +2190,28 @@ __global__ __launch_bounds__(256) void top16_counts_kernel(const K* __restrict__
     }
 }
 
+// Low-memory route: one round of the Regions level's block swaps (rdst_regions.cpp plans them; the ranges of one round
+// are pairwise disjoint).  One workgroup per chunk of at most SWAP_CHUNK elements: exchange `len` elements at `a` and `b`.
+// Device twin of the parallel `swap_with_slice` round of src/sorts/regions_sort.rs:247-251.
+constexpr uint32_t SWAP_CHUNK = 8192;
+struct SwapChunk { uint64_t a, b; uint32_t len, pad; };
+
+template <typename K>
+__global__ __launch_bounds__(256) void swap_ranges_kernel(K* __restrict__ keys, const SwapChunk* __restrict__ chunks) {
+    const SwapChunk c = chunks[blockIdx.x];
+    K* pa = keys + c.a;
+    K* pb = keys + c.b;
+    for (uint32_t i = threadIdx.x; i < c.len; i += 256 * 4) {
+        K va[4], vb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i + u * 256 < c.len) { va[u] = pa[i + u * 256]; vb[u] = pb[i + u * 256]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i + u * 256 < c.len) { pa[i + u * 256] = vb[u]; pb[i + u * 256] = va[u]; }
+    }
+}
+
 __global__ void raise_error_kernel(uint32_t* err, uint32_t bits) { atomicOr(err, bits); }  // rdst_hip_debug_raise_device_error
 
 // K6: one level's histogram + "digit sequence has an inversion" flag
@@ -2898,6 +2920,138 @@ int check_common(const void* p, uint64_t len, uint32_t elem_bytes, rdst_key_kind
     return RDST_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// Low-memory route (rdst_hip_sort_device_lowmem, rdst_hip_partition_device): host drivers.  Blocking by design: the swap
+// plan of a Regions level is made on the host from the tile x digit counts, as the reference makes it serially
+// (src/sorts/regions_sort.rs:235-239).
+// ------------------------------------------------------------------------------------------
+struct DeviceBuf {  // a hipMalloc that frees itself
+    void* p = nullptr;
+    ~DeviceBuf() { if (p) (void)hipFree(p); }
+};
+
+// Step (1) of a Regions level + its counts: every tile of `tile_len` keys grouped by digit `level` through `tmp`
+// (one K3 pass tile -> tmp, copied back), the 256 digit counts of tile t in counts_host[t * 256 ..].
+template <typename K, int LV>
+int regions_group_tiles(K* keys, uint64_t n, rdst_key_kind kind, uint32_t level, K* tmp, uint64_t tile_len, std::vector<uint64_t>& counts_host,
+                        hipStream_t s) {
+    const uint64_t tiles = (n + tile_len - 1) / tile_len;
+    DeviceBuf dcounts;
+    HIP_TRY(hipMalloc(&dcounts.p, sizeof(uint64_t) * RADIX * tiles));
+    for (uint64_t t = 0; t < tiles; ++t) {
+        K* tile = keys + t * tile_len;
+        const uint64_t tn = t + 1 < tiles ? tile_len : n - t * tile_len;
+        Layout L;
+        char* ws = nullptr;
+        int rc = run_pipeline<K, LV>(tile, tmp, tn, kind, level, level + 1, false, false, s, &L, &ws);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(static_cast<uint64_t*>(dcounts.p) + t * RADIX, ws + L.off_hist + sizeof(uint64_t) * (size_t)level * RADIX,
+                               sizeof(uint64_t) * RADIX, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(tile, tmp, sizeof(K) * tn, hipMemcpyDeviceToDevice, s));
+        DeviceState* D;
+        if ((rc = current_device_state(&D))) return rc;
+        if ((rc = workspace_release(*D, s))) return rc;  // the count copy reads the workspace
+    }
+    counts_host.resize(RADIX * tiles);
+    HIP_TRY(hipMemcpyAsync(counts_host.data(), dcounts.p, sizeof(uint64_t) * RADIX * tiles, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return RDST_OK;
+}
+
+// Steps (2)+(3): plan the swaps for the given columns and run them, round by round.  starts[buckets + 1]: region borders.
+template <typename K>
+int regions_swap(K* keys, uint64_t n, uint64_t tile_len, const std::vector<uint64_t>& col_counts, uint32_t columns, const uint32_t* col_bucket,
+                 uint32_t buckets, std::vector<uint64_t>& starts, hipStream_t s) {
+    const uint64_t tiles = (n + tile_len - 1) / tile_len;
+    std::vector<rdst_swap_op> ops(4 * tiles * columns + 4 * (uint64_t)buckets * buckets + 16);
+    constexpr uint32_t MAX_ROUNDS = 4096;
+    std::vector<uint64_t> rounds(MAX_ROUNDS + 1);
+    uint64_t nops = 0;
+    uint32_t nrounds = 0;
+    starts.assign(buckets + 1, 0);
+    if (rdst_regions_plan(col_counts.data(), tiles, tile_len, n, columns, col_bucket, buckets, ops.data(), ops.size(), &nops, rounds.data(),
+                          MAX_ROUNDS, &nrounds, starts.data()) != RDST_OK)
+        return fail(RDST_ERR_DEVICE, "regions plan: the tile counts are inconsistent");
+    if (nops == 0) return RDST_OK;
+    std::vector<SwapChunk> chunks;
+    std::vector<uint64_t> round_chunk(nrounds + 1, 0);
+    for (uint32_t r = 0; r < nrounds; ++r) {
+        for (uint64_t i = rounds[r]; i < rounds[r + 1]; ++i)
+            for (uint64_t off = 0; off < ops[i].len; off += SWAP_CHUNK) {
+                const uint64_t m = ops[i].len - off < SWAP_CHUNK ? ops[i].len - off : SWAP_CHUNK;
+                chunks.push_back({ops[i].a + off, ops[i].b + off, (uint32_t)m, 0});
+            }
+        round_chunk[r + 1] = chunks.size();
+    }
+    DeviceBuf dchunks;
+    HIP_TRY(hipMalloc(&dchunks.p, sizeof(SwapChunk) * chunks.size()));
+    HIP_TRY(hipMemcpyAsync(dchunks.p, chunks.data(), sizeof(SwapChunk) * chunks.size(), hipMemcpyHostToDevice, s));
+    for (uint32_t r = 0; r < nrounds; ++r) {
+        const uint64_t c0 = round_chunk[r], c1 = round_chunk[r + 1];
+        for (uint64_t c = c0; c < c1; c += (1u << 30)) {  // (a grid dimension holds 2^31 - 1 blocks)
+            const uint64_t m = c1 - c < (1u << 30) ? c1 - c : (1u << 30);
+            hipLaunchKernelGGL((swap_ranges_kernel<K>), dim3((uint32_t)m), dim3(256), 0, s, keys, static_cast<const SwapChunk*>(dchunks.p) + c);
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipStreamSynchronize(s));  // `chunks` and the device list go out of scope
+    return RDST_OK;
+}
+
+// Sort keys[0, n) by levels [0, level] in place, given that all its keys agree on the levels above `level`.
+template <typename K, int LV>
+int lowmem_sort(K* keys, uint64_t n, rdst_key_kind kind, int level, K* tmp, uint64_t tmp_len, hipStream_t s) {
+    if (n <= 1 || level < 0) return RDST_OK;
+    if (n <= tmp_len)  // fits the scratch: the ordinary route on the levels that are left (a constant level is skipped by the plan)
+        return run_pipeline<K, LV>(keys, tmp, n, kind, 0, (uint32_t)level + 1, true, true, s, nullptr, nullptr);
+    std::vector<uint64_t> counts;
+    int rc = regions_group_tiles<K, LV>(keys, n, kind, (uint32_t)level, tmp, tmp_len, counts, s);
+    if (rc) return rc;
+    std::vector<uint64_t> starts;
+    if ((rc = regions_swap<K>(keys, n, tmp_len, counts, RADIX, nullptr, RADIX, starts, s))) return rc;
+    // every digit now lies in its region.  Neighbouring regions that fit the scratch together are sorted in one call (all
+    // levels up to `level`: the call spans several digits); a region that does not fit takes another Regions level.
+    uint32_t d = 0;
+    while (d < (uint32_t)RADIX) {
+        const uint64_t lo = starts[d];
+        uint64_t size = starts[d + 1] - lo;
+        if (size > tmp_len) {
+            if ((rc = lowmem_sort<K, LV>(keys + lo, size, kind, level - 1, tmp, tmp_len, s))) return rc;
+            ++d;
+            continue;
+        }
+        uint32_t e = d + 1;
+        while (e < (uint32_t)RADIX && starts[e + 1] - lo <= tmp_len) ++e;
+        size = starts[e] - lo;
+        if (size > 1 && (rc = run_pipeline<K, LV>(keys + lo, tmp, size, kind, 0, (uint32_t)level + 1, true, true, s, nullptr, nullptr))) return rc;
+        d = e;
+    }
+    return RDST_OK;
+}
+
+template <typename K, int LV>
+int lowmem_entry(void* dev_keys, uint64_t len, rdst_key_kind kind, void* dev_tmp, uint64_t tmp_len, hipStream_t s) {
+    return lowmem_sort<K, LV>(static_cast<K*>(dev_keys), len, kind, LV - 1, static_cast<K*>(dev_tmp), tmp_len, s);
+}
+template <typename K, int LV>
+int partition_entry(void* dev_keys, uint64_t len, rdst_key_kind kind, uint32_t level, uint32_t digit, void* dev_tmp, uint64_t tmp_len,
+                    uint64_t* split_out, hipStream_t s) {
+    std::vector<uint64_t> counts;
+    int rc = regions_group_tiles<K, LV>(static_cast<K*>(dev_keys), len, kind, level, static_cast<K*>(dev_tmp), tmp_len, counts, s);
+    if (rc) return rc;
+    // a tile lies as [digits below][the digit][digits above]: three columns, two buckets (the digit first)
+    const uint64_t tiles = (len + tmp_len - 1) / tmp_len;
+    std::vector<uint64_t> cols(3 * tiles, 0);
+    for (uint64_t t = 0; t < tiles; ++t)
+        for (uint32_t d = 0; d < (uint32_t)RADIX; ++d) cols[3 * t + (d < digit ? 0 : (d == digit ? 1 : 2))] += counts[t * RADIX + d];
+    const uint32_t col_bucket[3] = {1, 0, 1};
+    std::vector<uint64_t> starts;
+    if ((rc = regions_swap<K>(static_cast<K*>(dev_keys), len, tmp_len, cols, 3, col_bucket, 2, starts, s))) return rc;
+    *split_out = starts[1];
+    return RDST_OK;
+}
+uint64_t usable_scratch(uint64_t tmp_len) { return tmp_len / 4096 * 4096; }  // tiles start on 16-byte boundaries for every key width
+
 int read_device_error(DeviceState& D, hipStream_t s) {
     if (!D.err_dev) return RDST_OK;
     HIP_TRY(hipMemcpyAsync(D.host_err, D.err_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -3423,6 +3577,47 @@ int rdst_hip_scatter_level(const void* dev_src, void* dev_dst, uint64_t len, uin
     DeviceState* D;
     rc = current_device_state(&D);
     if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(s));
+    return read_device_error(*D, s);
+}
+
+int rdst_hip_sort_device_lowmem(void* dev_keys, uint64_t len, uint32_t elem_bytes, rdst_key_kind kind, uint32_t levels, void* dev_tmp,
+                                uint64_t tmp_len, void* stream) {
+    int rc = check_common(dev_keys, len, elem_bytes, kind, levels);
+    if (rc) return rc;
+    if (len <= 1) return RDST_OK;
+    if (dev_tmp == nullptr) return fail(RDST_ERR_ARG, "null tmp pointer");
+    if (reinterpret_cast<uintptr_t>(dev_tmp) % elem_bytes) return fail(RDST_ERR_ALIGN, "tmp pointer not aligned to the element size");
+    tmp_len = usable_scratch(tmp_len);
+    if (tmp_len < 65536) return fail(RDST_ERR_ARG, "the scratch must hold at least 65536 elements");
+    std::lock_guard<std::mutex> lock(g_mutex);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    RDST_BY_WIDTH(elem_bytes, rc = (lowmem_entry<K, LV>(dev_keys, len, kind, dev_tmp, tmp_len, s)));
+    if (rc) return rc;
+    DeviceState* D;
+    if ((rc = current_device_state(&D))) return rc;
+    HIP_TRY(hipStreamSynchronize(s));
+    return read_device_error(*D, s);
+}
+
+int rdst_hip_partition_device(void* dev_keys, uint64_t len, uint32_t elem_bytes, rdst_key_kind kind, uint32_t level, uint32_t digit,
+                              void* dev_tmp, uint64_t tmp_len, uint64_t* split_out, void* stream) {
+    int rc = check_common(dev_keys, len, elem_bytes, kind, elem_bytes);
+    if (rc) return rc;
+    if (level >= elem_bytes || digit > 255) return fail(RDST_ERR_ARG, "level / digit out of range");
+    if (!split_out) return fail(RDST_ERR_ARG, "null split_out");
+    *split_out = 0;
+    if (len == 0) return RDST_OK;
+    if (dev_tmp == nullptr) return fail(RDST_ERR_ARG, "null tmp pointer");
+    if (reinterpret_cast<uintptr_t>(dev_tmp) % elem_bytes) return fail(RDST_ERR_ALIGN, "tmp pointer not aligned to the element size");
+    tmp_len = usable_scratch(tmp_len);
+    if (tmp_len < 65536) return fail(RDST_ERR_ARG, "the scratch must hold at least 65536 elements");
+    std::lock_guard<std::mutex> lock(g_mutex);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    RDST_BY_WIDTH(elem_bytes, rc = (partition_entry<K, LV>(dev_keys, len, kind, level, digit, dev_tmp, tmp_len, split_out, s)));
+    if (rc) return rc;
+    DeviceState* D;
+    if ((rc = current_device_state(&D))) return rc;
     HIP_TRY(hipStreamSynchronize(s));
     return read_device_error(*D, s);
 }

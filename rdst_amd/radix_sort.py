@@ -144,6 +144,47 @@ def sort_records_by_key(records, key_field):
     return records.index_select(0, idx.long() if idx.dtype != torch.int64 else idx)
 
 
+def sort_device_tensor_lowmem(keys, scratch=None):
+    """``rdst_hip_sort_device_lowmem``: sort a 1-D contiguous HIP tensor IN PLACE with a scratch of only ``scratch.numel()``
+    elements (default: len / 64, at least 65 536) instead of a second array — the device twin of the route
+    ``with_low_mem_tuner()`` selects in the reference (Regions / Ska: src/tuners/low_memory_tuner.rs:36-41,
+    src/sorts/regions_sort.rs:51-286).  Blocking.  Same result as :func:`sort_device_tensor`."""
+    import torch
+    if not keys.is_cuda or keys.dim() != 1 or not keys.is_contiguous():
+        raise ValueError("sort_device_tensor_lowmem needs a contiguous 1-D tensor on a HIP device")
+    kind, nbytes, levels = key_info(keys.dtype)
+    n = keys.numel()
+    if n <= 1:
+        return
+    if scratch is None:
+        scratch = torch.empty(max(65536, -(-n // 64)), dtype=keys.dtype, device=keys.device)
+    elif scratch.dtype != keys.dtype or scratch.device != keys.device or not scratch.is_contiguous():
+        raise ValueError("scratch must be a contiguous tensor of the same dtype and device")
+    lib = _lib.load()
+    with torch.cuda.device(keys.device):
+        _lib.check(lib.rdst_hip_sort_device_lowmem(ctypes.c_void_p(keys.data_ptr()), n, nbytes, kind, levels,
+                                                   ctypes.c_void_p(scratch.data_ptr()), scratch.numel(), _stream_handle(keys)))
+
+
+def partition_device(keys, level, digit, scratch=None):
+    """``rdst_hip_partition_device`` — ``partition_index`` (src/sort_utils.rs:295-331) with the predicate "digit `level` of
+    the key == `digit`": those keys first, the others after, in place; returns the split index.  Blocking."""
+    import torch
+    if not keys.is_cuda or keys.dim() != 1 or not keys.is_contiguous():
+        raise ValueError("partition_device needs a contiguous 1-D tensor on a HIP device")
+    kind, nbytes, _levels = key_info(keys.dtype)
+    n = keys.numel()
+    if scratch is None:
+        scratch = torch.empty(max(65536, -(-n // 64)), dtype=keys.dtype, device=keys.device)
+    split = ctypes.c_uint64(0)
+    lib = _lib.load()
+    with torch.cuda.device(keys.device):
+        _lib.check(lib.rdst_hip_partition_device(ctypes.c_void_p(keys.data_ptr()), n, nbytes, kind, int(level), int(digit),
+                                                 ctypes.c_void_p(scratch.data_ptr()), scratch.numel(), ctypes.byref(split),
+                                                 _stream_handle(keys)))
+    return int(split.value)
+
+
 def device_status(device=None):
     """Block on the current stream and raise if a kernel reported failure."""
     import torch
@@ -253,6 +294,17 @@ class RadixSortBuilder:
         except Exception:  # noqa: BLE001
             collective = False
         if n <= 1 and not collective:  # radix_sort_builder.rs:151 (a rank's shard of a distributed array may be empty)
+            return
+        if isinstance(self._tuner, LowMemoryTuner) and not self._key:
+            # with_low_mem_tuner(): the reference trades speed for memory (Ska / Regions instead of the out-of-place
+            # sorts, src/tuners/low_memory_tuner.rs:13-43); so does the device: in place, scratch of len / 64 elements
+            import torch
+            if _is_torch_tensor(self._data):
+                sort_device_tensor_lowmem(self._data)
+            else:
+                dev = torch.from_numpy(self._data.view(_same_width_int(self._data.dtype))).cuda().view(getattr(torch, self._data.dtype.name))
+                sort_device_tensor_lowmem(dev)
+                self._data.view(_same_width_int(self._data.dtype))[:] = dev.view(getattr(torch, np.dtype(_same_width_int(self._data.dtype)).name)).cpu().numpy()
             return
         if not isinstance(self._tuner, GpuTuner):
             if self._key:
