@@ -101,6 +101,7 @@ class RadixSortBuilder {  // src/radix_sort_builder.rs:8-158
     std::size_t len_;
     bool multi_threaded_ = true;          // accepted for source compatibility; the device route has no use for it
     bool device_default_ = true;          // no tuner chosen: the slice goes to the device
+    bool low_memory_ = false;             // with_low_mem_tuner(): the device's low-memory route
     const tuner::Tuner* tuner_ = nullptr;
 
    public:
@@ -109,9 +110,11 @@ class RadixSortBuilder {  // src/radix_sort_builder.rs:8-158
     }
     RadixSortBuilder& with_parallel(bool parallel) { multi_threaded_ = parallel; return *this; }
     RadixSortBuilder& with_tuner(const tuner::Tuner* t) { tuner_ = t; device_default_ = false; return *this; }
-    // with_low_mem_tuner / with_single_threaded_tuner select among the reference's CPU algorithms;
-    // they are not shipped here, so (like a user tuner that answers with a CPU algorithm) sort() throws.
-    RadixSortBuilder& with_low_mem_tuner() { static const tuner::LowMemoryTuner t; return with_tuner(&t); }
+    // with_low_mem_tuner (src/radix_sort_builder.rs:74-77) trades speed for memory in the reference (Ska / Regions instead of
+    // the out-of-place sorts): so does the device route — the keys and a scratch of len / 64 elements instead of two arrays
+    // (rdst_hip_sort_device_lowmem behind rdst_hip_opts::low_memory).  with_single_threaded_tuner selects among the
+    // reference's CPU algorithms, which are not shipped here: like a user tuner that answers with a CPU algorithm, sort() throws.
+    RadixSortBuilder& with_low_mem_tuner() { low_memory_ = true; tuner_ = nullptr; device_default_ = true; return *this; }
     RadixSortBuilder& with_single_threaded_tuner() { static const tuner::SingleThreadedTuner t; return with_tuner(&t); }
 
     void sort() {
@@ -127,7 +130,8 @@ class RadixSortBuilder {  // src/radix_sort_builder.rs:8-158
             if (a != tuner::Algorithm::GpuLsd && a != tuner::Algorithm::GpuSharded)
                 throw Error(RDST_ERR_UNSUPPORTED, "tuner picked a CPU algorithm: those stay in the reference crate; this header ships the device route only");
         }
-        const int rc = rdst_hip_sort(data_, len_, sizeof(T), RadixKey<T>::kind, RadixKey<T>::LEVELS, nullptr);
+        rdst_hip_opts opts{-1, low_memory_ ? 1 : 0, 0};
+        const int rc = rdst_hip_sort(data_, len_, sizeof(T), RadixKey<T>::kind, RadixKey<T>::LEVELS, &opts);
         if (rc != RDST_OK) throw Error(rc, rdst_hip_last_error());
     }
 

@@ -104,7 +104,9 @@ typedef enum {
 /* Options of the host entry point.  NULL = defaults. */
 typedef struct {
     int32_t  device;       /* HIP device ordinal, -1 = current device */
-    int32_t  reserved0;
+    int32_t  low_memory;   /* != 0: the low-memory route (rdst_hip_sort_device_lowmem): the device holds the keys and a scratch of
+                              len / 64 elements instead of two arrays — what `with_low_mem_tuner()` asks for
+                              (src/radix_sort_builder.rs:74-77) */
     uint64_t reserved1;
 } rdst_hip_opts;
 

@@ -61,7 +61,7 @@ class TuningParamsC(ctypes.Structure):
 
 
 class HipOptsC(ctypes.Structure):
-    _fields_ = [("device", ctypes.c_int32), ("reserved0", ctypes.c_int32), ("reserved1", ctypes.c_uint64)]
+    _fields_ = [("device", ctypes.c_int32), ("low_memory", ctypes.c_int32), ("reserved1", ctypes.c_uint64)]
 
 
 class RdstHipError(RuntimeError):

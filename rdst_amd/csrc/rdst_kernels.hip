@@ -3380,7 +3380,11 @@ int rdst_hip_sort(void* host_data, uint64_t len, uint32_t elem_bytes, rdst_key_k
         HIP_TRY(hipSetDevice(opts->device));
     }
     const size_t bytes = (size_t)len * elem_bytes;
+    const bool low_memory = opts && opts->low_memory != 0;
+    // low-memory route: the scratch is len / 64 elements (at least 65 536) instead of a second array
+    const uint64_t scratch_len = low_memory ? (len / 64 > 65536 ? len / 64 : 65536) : len;
     const size_t half = align_up(bytes, 256);
+    const size_t second = low_memory ? align_up((size_t)scratch_len * elem_bytes, 256) : half;
     // Stream and device buffer (keys + tmp) are kept per device: hipMalloc / hipFree pairs and a stream
     // per call were most of the 0.55 ms this entry point cost on small slices.  (A stream-ordered pool
     // allocation per call was tried first: with the system HIP runtime a sort whose buffer the pool
@@ -3406,10 +3410,10 @@ int rdst_hip_sort(void* host_data, uint64_t len, uint32_t elem_bytes, rdst_key_k
     static const bool pool_nofree = alloc_mode && strcmp(alloc_mode, "pool_nofree") == 0;  // blocks are never returned: no recycling
     void* pool_buf = nullptr;
     if (use_pool) {
-        if ((e = hipMallocAsync(&pool_buf, 2 * half, s)) != hipSuccess) return done(fail(RDST_ERR_HIP, "hipMallocAsync(keys + tmp)", e));
-    } else if (D->host_buf_bytes < 2 * half) {
+        if ((e = hipMallocAsync(&pool_buf, half + second, s)) != hipSuccess) return done(fail(RDST_ERR_HIP, "hipMallocAsync(keys + tmp)", e));
+    } else if (D->host_buf_bytes < half + second) {
         if (D->host_buf) { (void)hipStreamSynchronize(s); (void)hipFree(D->host_buf); D->host_buf = nullptr; D->host_buf_bytes = 0; }
-        const size_t want = 2 * half < (size_t)(64u << 20) ? 2 * half + (2 * half) / 2 : 2 * half;  // head room for small slices only
+        const size_t want = half + second < (size_t)(64u << 20) ? (half + second) + (half + second) / 2 : half + second;  // head room for small slices only
         if ((e = hipMalloc(&D->host_buf, want)) != hipSuccess) return done(fail(RDST_ERR_HIP, "hipMalloc(keys + tmp)", e));
         D->host_buf_bytes = want;
     }
@@ -3429,7 +3433,8 @@ int rdst_hip_sort(void* host_data, uint64_t len, uint32_t elem_bytes, rdst_key_k
                 (void*)(static_cast<char*>(D->ws) + D->ws_bytes));
         fflush(stderr);
     }
-    rc = rdst_hip_sort_device(d_keys, d_tmp, len, elem_bytes, kind, levels, s);
+    if (low_memory) rc = rdst_hip_sort_device_lowmem(d_keys, len, elem_bytes, kind, levels, d_tmp, scratch_len, s);
+    else rc = rdst_hip_sort_device(d_keys, d_tmp, len, elem_bytes, kind, levels, s);
     if (host_debug) {
         fprintf(stderr, "[host]   after enqueue: ws=[%p,%p) rc=%d\n", D->ws, (void*)(static_cast<char*>(D->ws) + D->ws_bytes), rc);
         fflush(stderr);

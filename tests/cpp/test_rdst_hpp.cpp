@@ -102,9 +102,20 @@ int main() {
         bad += check_float<float, std::uint32_t>(n, 5) + check_float<double, std::uint64_t>(n, 6);
         bad += check_int<std::uint8_t>(n, 7) + check_int<std::int16_t>(n, 8);
     }
+    // with_low_mem_tuner(): the device's low-memory route (src/radix_sort_builder.rs:74-77), same answer
+    {
+        PROGRESS("low-memory route", 3000001);
+        std::mt19937_64 rng(99);
+        std::vector<std::uint64_t> v(3000001);
+        for (auto& x : v) x = rng();
+        auto expect = v;
+        std::sort(expect.begin(), expect.end());
+        rdst::radix_sort_builder(v).with_low_mem_tuner().sort();
+        bad += !(v == expect);
+    }
     // a CPU tuner cannot be honoured here: throws, data untouched
     std::vector<std::uint32_t> keep = {9, 8, 7, 6};
-    try { rdst::radix_sort_builder(keep).with_low_mem_tuner().sort(); ++bad; } catch (const rdst::Error&) {}
+    try { rdst::radix_sort_builder(keep).with_single_threaded_tuner().sort(); ++bad; } catch (const rdst::Error&) {}
     bad += !(keep == std::vector<std::uint32_t>{9, 8, 7, 6});
     rdst::tuner::GpuTuner gpu(2);
     rdst::radix_sort_builder(keep).with_tuner(&gpu).sort();
