@@ -302,7 +302,8 @@ int rdst_hip_profile_run_stages(int run, uint32_t* stages_out, uint32_t capacity
  * src/tuners/standard_tuner.rs:46-62 picks by length and counts, too).  enabled == 0: LSD route always;
  * enabled == 2: hybrid route, but 4-byte keys also use the generic ranked in-LDS sort instead of the
  * counting sort by value; enabled == 3: counting sort, but pass L-1 hands it whole keys instead of the 16-bit low
- * halves it normally leaves in the workspace (A/B and tests).
+ * halves it normally leaves in the workspace; enabled == 5: no key sample before K1h; enabled == 6: 8-byte keys with the
+ * one-block-per-CU form of the in-LDS sort (A/B and tests).
  * min_len == 0 keeps the built-in threshold (2^28).  Results are identical on either route.
  * Not part of the reference surface. */
 int rdst_hip_set_hybrid(int enabled, uint64_t min_len);

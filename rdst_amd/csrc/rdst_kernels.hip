@@ -2067,6 +2067,166 @@ __global__ __launch_bounds__(WIDE_THREADS, 4) void local_wide_sort_kernel(
 
 
 
+// K4 for 8-byte keys, two workgroups per CU.  As local_wide_sort_kernel above, made to fit twice: the prefix table per PAIR
+// of counter words (8 KiB; a key in the odd word adds the even word's nibbles),
+// and for the tie order only bits [16, 32) of the low half in LDS (32 KiB instead of 64): 72 KiB per block.  Two members of
+// a group that agree on those 16 bits as well cannot be ordered from what is staged — about one bucket in seventy on uniform
+// keys — and such a bucket is left untouched for the generic kernel, like one whose counters overflow.
+constexpr int WIDE2_THREADS = 1024;  // 16 keys per thread, 64 VGPRs: two blocks = 32 waves per CU (512 threads x 32 keys: 128 VGPRs, 16 waves: 5.29 ms)
+constexpr size_t wide2_lds_bytes() { return 32768 + 8192 + 2 * (size_t)local_tile(8) + 128; }
+
+template <bool MAPPED>
+__global__ __launch_bounds__(WIDE2_THREADS, 8) void local_wide2_sort_kernel(
+    uint64_t* __restrict__ buf_keys, uint64_t* __restrict__ buf_tmp, const uint32_t* __restrict__ bstart, const Plan* __restrict__ plan,
+    uint32_t* __restrict__ err, uint64_t neg, uint64_t pos, uint32_t* __restrict__ list, uint32_t* __restrict__ list_count) {
+    constexpr int TILE = local_tile(8);
+    constexpr int BLOCK = WIDE2_THREADS, MAXR = TILE / BLOCK, WPT = H16_BINS / BLOCK / 8, LOG_VPT = 6;
+    constexpr int HALF = TILE / 2;
+    static_assert((size_t)HALF * 8 <= 32768 + 8192 + 2 * (size_t)TILE, "output staging fits the dead tables");
+    if (!plan->local_sort) return;
+    uint64_t* __restrict__ buf = plan->result_in_tmp ? buf_tmp : buf_keys;
+    const uint32_t bucket = blockIdx.x;
+    const uint32_t start = bstart[bucket], cnt = bstart[bucket + 1] - start;
+    if (cnt <= 1) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (cnt > (uint32_t)TILE) {
+        if (tid == 0) atomicOr(err, ERR_LOCAL_OVERFLOW);
+        return;
+    }
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* cnt4 = reinterpret_cast<uint32_t*>(smem);                              // [WPT][BLOCK] eight 4-bit counters per word
+    uint16_t* prefix2 = reinterpret_cast<uint16_t*>(smem + 32768);                   // [WPT / 2][BLOCK] keys below the word pair
+    uint16_t* mid16 = reinterpret_cast<uint16_t*>(smem + 32768 + 8192);              // [TILE] bits [16, 32) of the keys at their slots
+    uint64_t* out64 = reinterpret_cast<uint64_t*>(smem);                             // [HALF] output staging (everything above is dead by then)
+    uint32_t* s_wsum = reinterpret_cast<uint32_t*>(smem + 32768 + 8192 + 2 * TILE);  // [8] wave sums, [16] overflow / ambiguity flag
+    __builtin_amdgcn_s_setprio(RDST_PRIO_LOAD);
+    const uint64_t* tsrc = buf + start;
+    uint64_t mk[MAXR];
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) {
+        const uint32_t idx = (uint32_t)tid + i * BLOCK;
+        mk[i] = tsrc[idx < cnt ? idx : cnt - 1];
+    }
+#pragma unroll
+    for (int k = 0; k < WPT; ++k) cnt4[k * BLOCK + tid] = 0;
+    if (tid == 0) s_wsum[16] = 0;
+    __syncthreads();
+    __builtin_amdgcn_s_setprio(0);
+    auto word_of = [](uint32_t v) -> uint32_t { return ((v >> 3) & (uint32_t)(WPT - 1)) * BLOCK + (v >> LOG_VPT); };
+    constexpr uint64_t LOW48 = (1ull << 48) - 1;  // per-key state rides in the key's top 16 bits (the bucket index, restored at the end)
+    bool flag = false;
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) {
+        const uint32_t idx = (uint32_t)tid + i * BLOCK;
+        if (idx < cnt) {
+            if constexpr (MAPPED) mk[i] = map_key<uint64_t>(mk[i], neg, pos);
+            const uint32_t v = (uint32_t)(mk[i] >> 32) & 0xFFFFu;
+            const uint32_t sh = (v & 7u) * 4u;
+            const uint32_t old = atomicAdd(&cnt4[word_of(v)], 1u << sh);
+            const uint32_t mine = (old >> sh) & 15u;
+            flag |= mine == 15u;
+            mk[i] = (mk[i] & LOW48) | ((uint64_t)mine << 48);
+        }
+    }
+    if (flag) s_wsum[16] = 1;
+    __syncthreads();
+    if (s_wsum[16]) {  // block-uniform: the bucket stays as it is, for the generic kernel
+        if (tid == 0) list[atomicAdd(list_count, 1u)] = bucket;
+        return;
+    }
+    {
+        uint32_t pre[WPT / 2];
+        uint32_t run = 0;
+#pragma unroll
+        for (int k = 0; k < WPT; ++k) {
+            if ((k & 1) == 0) pre[k >> 1] = run;
+            run = nibble_sum(cnt4[k * BLOCK + tid], run);
+        }
+        uint32_t incl = run;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(incl, o);
+            if (lane >= o) incl += y;
+        }
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        uint32_t base = incl - run;
+#pragma unroll
+        for (int x = 0; x < BLOCK / 64; ++x)
+            if (x < wave) base += s_wsum[x];
+#pragma unroll
+        for (int k = 0; k < WPT / 2; ++k) prefix2[k * BLOCK + tid] = (uint16_t)(base + pre[k]);
+    }
+    __syncthreads();
+    // first slot of a value: the pair's prefix, the even word's nibbles if the value sits in the odd word, the nibbles below it
+    auto first_slot = [&](uint32_t v, uint32_t w, uint32_t wd) -> uint32_t {
+        const uint32_t k = (v >> 3) & (uint32_t)(WPT - 1);
+        uint32_t at = prefix2[(k >> 1) * BLOCK + (v >> LOG_VPT)];
+        if (k & 1u) at = nibble_sum(cnt4[wd - BLOCK], at);
+        return nibble_sum(w & ((1u << ((v & 7u) * 4u)) - 1u), at);
+    };
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) {
+        const uint32_t idx = (uint32_t)tid + i * BLOCK;
+        if (idx < cnt) {
+            const uint32_t v = (uint32_t)(mk[i] >> 32) & 0xFFFFu, mine = (uint32_t)(mk[i] >> 48);
+            const uint32_t wd = word_of(v);
+            const uint32_t slot = first_slot(v, cnt4[wd], wd) + mine;
+            mid16[slot] = (uint16_t)((uint32_t)mk[i] >> 16);
+            mk[i] = (mk[i] & LOW48) | ((uint64_t)slot << 48);
+        }
+    }
+    __syncthreads();
+    // ties: my place inside my group = members with smaller bits [16, 32) (equal ones would need the low 16 bits: give up)
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) {
+        const uint32_t idx = (uint32_t)tid + i * BLOCK;
+        if (idx < cnt) {
+            const uint32_t v = (uint32_t)(mk[i] >> 32) & 0xFFFFu, slot = (uint32_t)(mk[i] >> 48);
+            const uint32_t wd = word_of(v);
+            const uint32_t w = cnt4[wd];
+            const uint32_t group = (w >> ((v & 7u) * 4u)) & 15u;
+            if (group >= 2u) {
+                const uint32_t first = first_slot(v, w, wd);
+                const uint32_t mid = (uint32_t)mk[i] >> 16;
+                uint32_t rank = 0;
+                for (uint32_t j = 0; j < group; ++j) {
+                    const uint32_t other = mid16[first + j];
+                    rank += other < mid ? 1u : 0u;
+                    flag |= other == mid && first + j != slot;
+                }
+                mk[i] = (mk[i] & LOW48) | ((uint64_t)(first + rank) << 48);
+            }
+        }
+    }
+    if (flag) s_wsum[16] = 1;
+    __syncthreads();  // every look at the tables and the staged bits is done: their space becomes the output staging
+    if (s_wsum[16]) {
+        if (tid == 0) list[atomicAdd(list_count, 1u)] = bucket;
+        return;
+    }
+    uint64_t* tdst = buf + start;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (h == 1 && cnt <= (uint32_t)HALF) break;  // block-uniform
+        __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i) {
+            const uint32_t idx = (uint32_t)tid + i * BLOCK;
+            const uint32_t rel = (uint32_t)(mk[i] >> 48) - (uint32_t)(h * HALF);
+            if (idx < cnt && rel < (uint32_t)HALF) out64[rel] = (mk[i] & LOW48) | ((uint64_t)bucket << 48);
+        }
+        __syncthreads();
+        __builtin_amdgcn_s_setprio(RDST_PRIO_SCATTER);
+#pragma unroll
+        for (int i = 0; i < HALF / BLOCK; ++i) {
+            const uint32_t rel = (uint32_t)tid + i * BLOCK, at = rel + (uint32_t)(h * HALF);
+            if (at < cnt) tdst[at] = MAPPED ? unmap_key<uint64_t>(out64[rel], neg, pos) : out64[rel];
+        }
+        if (h == 0) __syncthreads();  // the second half reuses the staging
+    }
+}
+
 // result sits in tmp after an odd number of executed passes: copy back
 // (src/sorts/lsb_sort.rs:117-126)
 template <typename K, int VEC>
@@ -2295,6 +2455,7 @@ struct Tuning {
     bool count_sort = true;             // 4-byte keys: K4 as a counting sort by value (false: the generic ranked passes)
     bool halves = true;                 // 4-byte keys: pass L-1 hands K4 the low halves only (16-bit array in the workspace)
     bool presample = true;              // a 65 536-key sample before K1h: gross skew goes straight to the LSD route
+    bool wide2 = true;                  // 8-byte keys: K4 as two 512-thread blocks per CU (false: one 1024-thread block)
     uint64_t hybrid_min_len = 1ull << 28;  // below this the buckets are too small for one workgroup each to pay off
 };
 uint32_t g_ablate = 0;  // only ever set by the RDST_EXPERIMENTS build
@@ -2570,7 +2731,16 @@ int launch_local_sort(K* keys, K* tmp, const uint32_t* bstart, const Plan* plan,
     if constexpr (sizeof(K) == 8) {
         if (g_tuning.count_sort) {
             constexpr size_t wlds = wide_lds_bytes();
-            if (mapped) {
+            if (g_tuning.wide2) {  // two 512-thread blocks per CU
+                constexpr size_t w2 = wide2_lds_bytes();
+                if (mapped) {
+                    if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_wide2_sort_kernel<true>), w2)) return rc;
+                    hipLaunchKernelGGL((local_wide2_sort_kernel<true>), dim3(H16_BINS), dim3(WIDE2_THREADS), w2, s, keys, tmp, bstart, plan, err, (uint64_t)km.neg, (uint64_t)km.pos, list, list_count);
+                } else {
+                    if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_wide2_sort_kernel<false>), w2)) return rc;
+                    hipLaunchKernelGGL((local_wide2_sort_kernel<false>), dim3(H16_BINS), dim3(WIDE2_THREADS), w2, s, keys, tmp, bstart, plan, err, (uint64_t)km.neg, (uint64_t)km.pos, list, list_count);
+                }
+            } else if (mapped) {
                 if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_wide_sort_kernel<true>), wlds)) return rc;
                 hipLaunchKernelGGL((local_wide_sort_kernel<true>), dim3(H16_BINS), dim3(WIDE_THREADS), wlds, s, keys, tmp, bstart, plan, err, (uint64_t)km.neg, (uint64_t)km.pos, list, list_count);
             } else {
@@ -3103,6 +3273,7 @@ int rdst_hip_set_hybrid(int enabled, uint64_t min_len) {
     g_tuning.count_sort = enabled != 2;  // 2: hybrid route with the generic local sort for every key width (A/B, tests)
     g_tuning.halves = enabled != 3;      // 3: counting K4 reading whole keys (no 16-bit hand-off) (A/B, tests)
     g_tuning.presample = enabled != 5;   // 5: no sample before K1h: every hybrid-eligible sort counts all its keys' prefixes first (tests)
+    g_tuning.wide2 = enabled != 6;       // 6: 8-byte keys with the one-block-per-CU form of K4 (A/B, tests)
     g_tuning.hybrid_min_len = min_len ? min_len : (1ull << 28);
     return RDST_OK;
 }

@@ -14,12 +14,12 @@ pytestmark = pytest.mark.gpu
 TILE = {4: 16896, 8: 16384}  # K4 tile = largest bucket the hybrid route accepts
 
 
-@pytest.fixture(params=["count", "count_whole_keys", "ranked"])
+@pytest.fixture(params=["count", "count_whole_keys", "ranked", "wide_one_block"])
 def hybrid(gpu, request):
     """the forms of K4 for 4-byte keys: the counting sort by value fed with the 16-bit halves pass L-1 leaves in the
-    workspace (default), the same fed with whole keys, and the generic ranked passes (what 8-byte keys always use,
+    workspace (default; 8-byte keys: two 512-thread blocks per CU, or — "wide_one_block" — one of 1024), the same fed with whole keys, and the generic ranked passes (what 8-byte keys always use,
     and the fallback for buckets whose counters overflow)"""
-    mode = {"count": True, "count_whole_keys": 3, "ranked": 2}[request.param]
+    mode = {"count": True, "count_whole_keys": 3, "ranked": 2, "wide_one_block": 6}[request.param]
     gpu.set_hybrid(mode, min_len=1)   # consider the route at every length (default: 2^28 and up)
     yield gpu
     gpu.set_hybrid(True, 0)
