@@ -94,12 +94,15 @@ typedef enum {
     RDST_STAGE_COPYBACK = 5,
     RDST_STAGE_HIST16 = 6,   /* K1h: counts of the top 16 bits (hybrid route) */
     RDST_STAGE_ROUTE = 7,    /* route decision + bucket starts */
-    RDST_STAGE_LOCAL = 8     /* K4: per-bucket sort of the remaining levels inside LDS (hybrid route) */
+    RDST_STAGE_LOCAL = 8,    /* K4: per-bucket sort of the remaining levels inside LDS (hybrid and atomic routes) */
+    RDST_STAGE_MSD_A = 10,   /* atomic route: scatter by the top byte into over-provisioned areas (claims instead of counts) */
+    RDST_STAGE_MSD_B = 11    /* atomic route: scatter of every area by the second byte into the bucket slots (low halves) */
 } rdst_stage;
 
 /* Device routes (rdst_hip_last_route). */
 #define RDST_ROUTE_LSD 0u     /* one scatter pass per level */
 #define RDST_ROUTE_HYBRID 1u  /* two scatter passes on the top 16 bits + one in-LDS sort per bucket */
+#define RDST_ROUTE_ATOMIC 2u  /* the same without the counting read: MSD passes that claim space with atomics (4-byte keys) */
 
 /* Options of the host entry point.  NULL = defaults. */
 typedef struct {

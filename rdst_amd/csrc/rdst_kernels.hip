@@ -86,7 +86,15 @@ constexpr uint32_t ERR_LOCAL_OVERFLOW = 4;  // a bucket of the hybrid route larg
 //                 65 536 buckets by the remaining levels inside LDS — one read and one coalesced write
 //                 instead of L-2 scatter passes (u32: 28 instead of 36 bytes per key; u64: 56 instead
 //                 of 136).  Taken when every bucket fits K4's tile; anything else goes the LSD way.
-constexpr uint32_t ROUTE_LSD = 0, ROUTE_HYBRID = 1;
+//   ROUTE_ATOMIC  (4-byte keys) the hybrid route without its counting read.  An MSD pass needs no stable order and no exact
+//                 global offsets up front, only ROOM: pass A scatters by the top byte into 256 x 8 over-provisioned areas
+//                 (digit x XCD slice) of the workspace, a tile claiming its space per digit with ONE returning global
+//                 atomic where K3 walks back over its predecessors; pass B scatters every area by the second byte into
+//                 65 536 slots of one K4 tile each (low halves only); K4 sorts each slot's bucket to its exact place
+//                 (exclusive scan of the 65 536 claim counters).  8 + 6 + 6 = 20 bytes per key.  Uniform keys never
+//                 overflow an area (capacity = mean + max(1 %, 8 sigma)); anything that does takes the LSD route.
+constexpr uint32_t ROUTE_LSD = 0, ROUTE_HYBRID = 1, ROUTE_ATOMIC = 2;
+constexpr int MSD_SLICES = 8;  // areas per top digit in pass A: blocks b and b + 8 share an XCD, so a digit's 8 frontiers stay with one L2 each
 constexpr int H16_BINS = 65536;
 
 struct Plan {
@@ -259,7 +267,7 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const K* __restrict_
                                                             const Plan* __restrict__ plan /* nullable: the hybrid route has its own counts (K1h) */,
                                                             int base_level /* table row and digit of this kernel's level 0 (one-level counts of a single pass: LEVELS == 1) */) {
     using P = HistPlan<LEVELS, PAIR>;
-    if (plan && (plan->route == ROUTE_HYBRID || plan->sorted_known)) return;  // (sorted: K2 turns every pass off whatever the counts)
+    if (plan && (plan->route != ROUTE_LSD || plan->sorted_known)) return;  // (sorted: K2 turns every pass off whatever the counts)
     constexpr int COPIES = P::COPIES, PCOPIES = P::PCOPIES, WORDS = P::WORDS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* s_h = reinterpret_cast<uint32_t*>(smem);
@@ -665,6 +673,62 @@ __global__ __launch_bounds__(1024) void route_kernel(RouteArgs a) {
     for (int j = tid; j < CHAINS * RADIX; j += 1024) a.hpos[(size_t)(top - 1) * CHAINS * RADIX + j] = a.hpos16[j];
 }
 
+// ROUTE_ATOMIC, after its two scatter passes: did every claim fit?  Then the 65 536 claim counters are the bucket lengths:
+// their exclusive scan gives every bucket's place in the sorted slice (thread t owns 64 buckets, as in route_kernel).
+struct MsdFinishArgs {
+    const uint32_t* cursor_b;   // [65536] keys claimed per slot
+    const uint32_t* overflow;
+    const uint32_t* inversion;
+    uint32_t* bstart;           // [65537] out
+    Plan* plan;
+    uint64_t n;
+    uint32_t allow_skip;
+};
+
+__global__ __launch_bounds__(1024) void msd_finish_kernel(MsdFinishArgs a) {
+    __shared__ uint32_t s_wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool sorted = a.allow_skip && *a.inversion == 0 && a.plan->gross_skew == 0 && *a.overflow == 0;
+    const bool ok = a.plan->gross_skew == 0 && *a.overflow == 0;
+    if (tid == 0) {
+        a.plan->route = ok ? ROUTE_ATOMIC : ROUTE_LSD;
+        a.plan->local_sort = ok && !sorted ? 1u : 0u;
+        a.plan->sorted_known = sorted ? 1u : 0u;
+    }
+    if (!ok || sorted) return;
+    uint32_t c[64];
+    const uint4* src = reinterpret_cast<const uint4*>(a.cursor_b) + (size_t)tid * 16;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const uint4 v = src[k];
+        c[4 * k] = v.x; c[4 * k + 1] = v.y; c[4 * k + 2] = v.z; c[4 * k + 3] = v.w;
+    }
+    uint32_t mine = 0;
+#pragma unroll
+    for (int k = 0; k < 64; ++k) mine += c[k];
+    uint32_t incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(incl, o);
+        if (lane >= o) incl += y;
+    }
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    uint32_t run = incl - mine;
+    for (int w = 0; w < wave; ++w) run += s_wsum[w];
+    uint4* dst = reinterpret_cast<uint4*>(a.bstart) + (size_t)tid * 16;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        uint4 v;
+        v.x = run; run += c[4 * k];
+        v.y = run; run += c[4 * k + 1];
+        v.z = run; run += c[4 * k + 2];
+        v.w = run; run += c[4 * k + 3];
+        dst[k] = v;
+    }
+    if (tid == 1023) a.bstart[H16_BINS] = run;  // == n
+}
+
 // ------------------------------------------------------------------------------------------
 // K2: one block of 256 threads.  Digit totals of every level (sum of the range tables), their
 // exclusive scan -> bucket start table, the skip plan, and for every executed level the chain
@@ -729,8 +793,9 @@ __global__ __launch_bounds__(256 * SCAN_GROUPS) void scan_kernel(ScanArgs a) {
         const bool already_sorted = a.allow_skip && *a.inversion == 0;  // nothing to do at all
         // hybrid route: only the two top levels are scatter passes, K4 does the rest
         const bool hybrid = a.plan->route == ROUTE_HYBRID;
-        const uint32_t level_lo = hybrid ? a.levels - 2 : a.level_lo;
-        a.plan->local_sort = hybrid && !already_sorted ? 1u : 0u;
+        const bool atomic_done = a.plan->route == ROUTE_ATOMIC;  // its own kernels did (or do) everything: no scatter pass of K3 runs
+        const uint32_t level_lo = hybrid ? a.levels - 2 : (atomic_done ? a.levels : a.level_lo);
+        if (!atomic_done) a.plan->local_sort = hybrid && !already_sorted ? 1u : 0u;
         for (uint32_t l = 0; l < MAX_LEVELS; ++l) {
             const bool active = l >= level_lo && l < a.level_hi && l < a.levels;
             const bool needed = hybrid && a.halves && l + 1 == a.levels;
@@ -1425,6 +1490,228 @@ ranked:
 }
 
 // ------------------------------------------------------------------------------------------
+// MSD scatter with claimed space (ROUTE_ATOMIC).  The tile part is K3's — wave-striped load, per-wave LDS histograms,
+// tile scan, ranking by returning LDS add (no order test: an MSD pass has nothing to preserve), whole tile staged, runs
+// stored by consecutive threads — without tickets, chains, status rows or look-back: thread d claims the tile's run of
+// digit d with `atomicAdd(&cursor[area of d], count)`.  Sources are `areas` of `area_cap` slots each, area a holding
+// area_count[a] keys (pass A: ONE area, the input slice itself; pass B: the 2 048 areas pass A filled); tile j of area a
+// is block a * tiles_per_area + j.  Destinations: pass A: area (digit, blockIdx % 8) of dst_cap keys; pass B: slot
+// (top digit of the source area, digit) of dst_cap keys, low halves only (HALVES).  A claim that would pass the capacity
+// raises *overflow and stores nothing.  The key map is applied for the digit and, for whole keys, undone at the store.
+// ------------------------------------------------------------------------------------------
+template <int KPT, int NWAVES, bool MAPPED, bool HALVES>
+__global__ __launch_bounds__(NWAVES * 64, (2 * NWAVES + 3) / 4) void msd_scatter_kernel(
+    const uint32_t* __restrict__ src, const uint32_t* __restrict__ area_count /* nullable: one area of n keys */, uint64_t n, uint32_t area_cap,
+    uint32_t tiles_per_area, uint32_t* __restrict__ dst, uint16_t* __restrict__ dst16, uint32_t* __restrict__ cursor, uint32_t dst_cap, int shift,
+    const Plan* __restrict__ plan, uint32_t* __restrict__ overflow, uint32_t* __restrict__ inversion /* pass A sets it; pass B reads it */,
+    uint32_t neg, uint32_t pos) {
+    using K = uint32_t;
+    constexpr int BLOCK = NWAVES * 64, TILE = BLOCK * KPT;
+    constexpr uint32_t SLOT_UNIT = 4;
+    if (plan->gross_skew || *overflow) return;  // the sample or an earlier pass already gave the route up
+    if (HALVES && *inversion == 0) return;      // pass A met no inversion: the slice is sorted, nothing to do
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* wave_hist = reinterpret_cast<uint32_t*>(smem);                           // [NWAVES][256]
+    uint32_t* s_delta = reinterpret_cast<uint32_t*>(smem + NWAVES * 1024);             // [256] destination of tile slot 0 of a digit's run (elements, mod 2^32)
+    uint32_t* s_misc = reinterpret_cast<uint32_t*>(smem + NWAVES * 1024 + 1024);       // [16]
+    K* s_keys = reinterpret_cast<K*>(smem + NWAVES * 1024 + 1024 + 64);                // [TILE]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t area = blockIdx.x / tiles_per_area, j = blockIdx.x % tiles_per_area;
+    const uint64_t acount = area_count ? (uint64_t)area_count[area] : n;
+    const uint64_t tile_off = (uint64_t)j * TILE;
+    if (tile_off >= acount) return;
+    const uint32_t valid = acount - tile_off < (uint64_t)TILE ? (uint32_t)(acount - tile_off) : (uint32_t)TILE;
+    const bool full = valid == (uint32_t)TILE;
+    const K* tsrc = src + (uint64_t)area * area_cap + tile_off;
+    __builtin_amdgcn_s_setprio(RDST_PRIO_LOAD);
+    K mk[KPT];
+    const uint32_t wbase = (uint32_t)wave * 64u * KPT + (uint32_t)lane;
+    // pass A reads the caller's slice in its order: the already-sorted exit (src/sorter.rs:59-65) looks here.  Index order is
+    // (wave, round, lane): the key before a wave's first is fetched with the tile (one lane), the others are in registers
+    K edge = 0;
+    if constexpr (!HALVES) {
+        if (lane == 0 && tile_off + (uint64_t)wave * 64u * KPT > 0 && (uint32_t)wave * 64u * KPT < valid) edge = tsrc[(int64_t)wbase - 1];
+    }
+    if (full) {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) mk[i] = tsrc[wbase + i * 64];
+        if constexpr (MAPPED) {
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) mk[i] = map_key<K>(mk[i], neg, pos);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const uint32_t idx = wbase + i * 64;
+            K v = (K)~(K)0;  // digit 255 and the largest key: ranked (stably) after the real keys of the tile, never stored
+            if (idx < valid) {
+                v = tsrc[idx];
+                if constexpr (MAPPED) v = map_key<K>(v, neg, pos);
+            }
+            mk[i] = v;
+        }
+    }
+    if constexpr (!HALVES) {
+        if constexpr (MAPPED) edge = map_key<K>(edge, neg, pos);
+        if (tile_off + (uint64_t)wave * 64u * KPT == 0) edge = 0;  // the slice's first key has no predecessor
+        bool inv = false;
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            K before = lane_below<K>(mk[i]);
+            if (lane == 0) before = i == 0 ? edge : (K)__builtin_amdgcn_readlane((int)mk[i > 0 ? i - 1 : 0], 63);
+            inv |= before > mk[i];  // (padding is the largest key and sits at the end: it never counts as an inversion)
+        }
+        if (__builtin_amdgcn_ballot_w64(inv) != 0 && lane == 0) atomicOr(inversion, 1u);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    uint32_t* wh = wave_hist + wave * RADIX;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wh[lane + 64 * q] = 0;
+    const int bit0 = shift & 31;
+    uint32_t uniform_rounds = 0;
+    uint32_t run_index[(KPT + 1) / 2];
+    bool careful, fast;
+    {
+        const uint32_t d0 = digit_of(mk[0], shift);
+        const uint32_t dn = (uint32_t)__builtin_amdgcn_mov_dpp((int)d0, 0x138, 0xf, 0xf, false);
+        careful = __builtin_popcountll(__builtin_amdgcn_ballot_w64(d0 == dn) & ~1ull) >= 8;
+        fast = !careful && full;  // any order inside a run will do (no order test) — but a partial tile's padding must stay BEHIND
+                                  // the real keys of digit 255, which only the stable forms below guarantee
+        if (careful) {
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                const uint32_t d = digit_of(mk[i], shift);
+                if (__all((int)(d == (uint32_t)__builtin_amdgcn_readfirstlane((int)d))) != 0) {
+                    if (lane == 0) wh[d] += 64u;
+                    uniform_rounds |= 1u << i;
+                } else {
+                    uint32_t total;
+                    const uint32_t below = peers_below_total(mk[i], bit0, total);
+                    if (below == 0) atomicAdd(&wh[d], total);
+                }
+            }
+        } else if (fast) {
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                const uint32_t r = atomicAdd(&wh[digit_of(mk[i], shift)], 1u);
+                if (i & 1) run_index[i >> 1] |= r << 16;
+                else run_index[i >> 1] = r;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) atomicAdd(&wh[digit_of(mk[i], shift)], 1u);
+        }
+    }
+    __syncthreads();
+    if (tid < RADIX) __builtin_amdgcn_s_setprio(RDST_PRIO_SCAN);
+    uint32_t cw[NWAVES];
+    uint32_t count_d = 0, pub = 0;
+    if (tid < RADIX) {
+#pragma unroll
+        for (int w = 0; w < NWAVES; ++w) {
+            cw[w] = wave_hist[w * RADIX + tid];
+            count_d += cw[w];
+        }
+        pub = count_d;
+        if (tid == RADIX - 1) pub -= (uint32_t)TILE - valid;  // the padding of a partial tile is not keys
+    }
+    uint32_t incl = count_d;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(incl, o);
+        if (lane >= o) incl += y;
+    }
+    if (tid < RADIX && lane == 63) s_misc[4 + wave] = incl;
+    if (tid == 0) s_misc[1] = 0;
+    __syncthreads();
+    if (tid < RADIX) {
+        uint32_t woff = 0;
+        for (int w = 0; w < wave; ++w) woff += s_misc[4 + w];
+        const uint32_t local_off = woff + incl - count_d;
+        uint32_t run = local_off;
+#pragma unroll
+        for (int w = 0; w < NWAVES; ++w) {
+            wave_hist[w * RADIX + tid] = run * SLOT_UNIT;
+            run += cw[w];
+        }
+        // claim the run's space: one returning atomic per digit and tile
+        const uint32_t where = HALVES ? (area / MSD_SLICES) * RADIX + (uint32_t)tid : (uint32_t)tid * MSD_SLICES + (blockIdx.x % MSD_SLICES);
+        uint32_t got = 0;
+        if (pub) {
+            got = atomicAdd(&cursor[where], pub);
+            if (got + pub > dst_cap) {  // no room: give the route up, store nothing of this tile
+                atomicOr(overflow, 1u);
+                s_misc[1] = 1;
+            }
+        }
+        s_delta[tid] = where * dst_cap + got - local_off;  // (mod 2^32; the destination arrays hold fewer than 2^32 elements)
+    }
+    __syncthreads();
+    __builtin_amdgcn_s_setprio(0);
+    if (fast) {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const uint32_t idx = (i & 1) ? (run_index[i >> 1] >> 16) : (run_index[i >> 1] & 0xFFFFu);
+            const uint32_t sl = wh[digit_of(mk[i], shift)] + idx * SLOT_UNIT;
+            *reinterpret_cast<K*>(reinterpret_cast<unsigned char*>(s_keys) + sl) = mk[i];
+        }
+    } else if (!careful) {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            uint32_t* slot = &wh[digit_of(mk[i], shift)];
+            const uint32_t b = *slot;
+            const uint32_t below = peers_below(mk[i], bit0);
+            __builtin_amdgcn_wave_barrier();
+            atomicAdd(slot, SLOT_UNIT);
+            *reinterpret_cast<K*>(reinterpret_cast<unsigned char*>(s_keys) + b + below * SLOT_UNIT) = mk[i];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            uint32_t* slot = &wh[digit_of(mk[i], shift)];
+            const uint32_t b = *slot;
+            uint32_t below;
+            if ((uniform_rounds >> i) & 1u) {
+                below = (uint32_t)lane;
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) *slot = b + 64u * SLOT_UNIT;
+            } else {
+                uint32_t total;
+                below = peers_below_total(mk[i], bit0, total);
+                __builtin_amdgcn_wave_barrier();
+                if (below == 0) *slot = b + total * SLOT_UNIT;
+            }
+            *reinterpret_cast<K*>(reinterpret_cast<unsigned char*>(s_keys) + b + below * SLOT_UNIT) = mk[i];
+        }
+    }
+    __syncthreads();
+    if (s_misc[1]) return;
+    __builtin_amdgcn_s_setprio(RDST_PRIO_SCATTER);
+    constexpr int SUB = KPT % 6 == 0 ? 6 : (KPT % 4 == 0 ? 4 : (KPT < 6 ? KPT : 6));
+#pragma unroll
+    for (int i0 = 0; i0 < KPT; i0 += SUB) {
+        K kk[SUB];
+        uint32_t dd[SUB];
+#pragma unroll
+        for (int i = 0; i < SUB; ++i)
+            if (i0 + i < KPT) kk[i] = s_keys[tid + (i0 + i) * BLOCK];
+#pragma unroll
+        for (int i = 0; i < SUB; ++i)
+            if (i0 + i < KPT) dd[i] = s_delta[digit_of(kk[i], shift)];
+#pragma unroll
+        for (int i = 0; i < SUB; ++i) {
+            if (i0 + i >= KPT) continue;
+            const uint32_t p = (uint32_t)tid + (uint32_t)(i0 + i) * BLOCK;  // slot in the tile; the padding sits at the end
+            if (full || p < valid) {
+                const uint32_t g = dd[i] + p;
+                if constexpr (HALVES) dst16[g] = (uint16_t)kk[i];
+                else dst[g] = MAPPED ? unmap_key<K>(kk[i], neg, pos) : kk[i];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Small slices: the whole LSD sort in one workgroup.  Up to 64 KiB of keys live in registers
 // (wave-striped like a K3 tile) and are re-ordered through LDS once per level with K3's counting,
 // scan and ballot ranking; no workspace, no look-back, one launch (~5 us per level instead of the
@@ -1536,7 +1823,7 @@ constexpr size_t local_lds_bytes(size_t key_bytes) { return (size_t)local_waves(
 
 template <typename K, int NWAVES, int KPT, bool MAPPED>
 __device__ __forceinline__ void local_sort_bucket(K* __restrict__ buf, const uint16_t* __restrict__ src16 /* nullable: low halves of the mapped keys */,
-                                                  const uint32_t bucket, const uint32_t start, const uint32_t cnt,
+                                                  const uint32_t soff /* where they lie in src16 */, const uint32_t bucket, const uint32_t start, const uint32_t cnt,
                                                   uint32_t* __restrict__ err, K neg, K pos, uint32_t flags) {
     constexpr int BLOCK = NWAVES * 64, TILE = BLOCK * KPT, W = sizeof(K) * 8, LOCAL = (int)sizeof(K) - 2;
     constexpr uint32_t SLOT_UNIT = (uint32_t)sizeof(K);  // running slots count in bytes of the staging buffer
@@ -1544,7 +1831,7 @@ __device__ __forceinline__ void local_sort_bucket(K* __restrict__ buf, const uin
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (cnt <= 1) {
         if (sizeof(K) == 4 && src16 && cnt == 1 && tid == 0) {  // the key exists only as its low half
-            const K m = (K)((K)bucket << (W - 16)) | (K)src16[start];
+            const K m = (K)((K)bucket << (W - 16)) | (K)src16[soff];
             buf[start] = MAPPED ? unmap_key<K>(m, neg, pos) : m;
         }
         return;
@@ -1574,7 +1861,7 @@ __device__ __forceinline__ void local_sort_bucket(K* __restrict__ buf, const uin
                 const uint32_t idx = wbase + i * 64;
                 const uint32_t at = idx < cnt ? idx : cnt - 1;
                 if (sizeof(K) == 4 && src16) {  // block-uniform
-                    if (idx < cnt) v = (K)((K)bucket << (W - 16)) | (K)src16[start + at];
+                    if (idx < cnt) v = (K)((K)bucket << (W - 16)) | (K)src16[soff + at];
                 } else {
                     const K raw = tsrc[at];
                     if (idx < cnt) v = MAPPED ? map_key<K>(raw, neg, pos) : raw;
@@ -1747,13 +2034,13 @@ template <typename K, int NWAVES, int KPT, bool MAPPED>
 __global__ __launch_bounds__(NWAVES * 64, (sizeof(K) <= 4 ? 2 : 1) * NWAVES / 4) void local_sort_kernel(
     K* __restrict__ buf_keys, K* __restrict__ buf_tmp, const uint32_t* __restrict__ bstart, const Plan* __restrict__ plan,
     uint32_t* __restrict__ err, K neg, K pos, uint32_t flags, const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count,
-    const uint16_t* __restrict__ src16) {
+    const uint16_t* __restrict__ src16, const uint32_t* __restrict__ slot_count, uint32_t slot_cap) {
     if (!plan->local_sort) return;
     K* __restrict__ buf = plan->result_in_tmp ? buf_tmp : buf_keys;
     if (list == nullptr) {
         const uint32_t bucket = blockIdx.x;
         const uint32_t start = bstart[bucket];
-        local_sort_bucket<K, NWAVES, KPT, MAPPED>(buf, src16, bucket, start, bstart[bucket + 1] - start, err, neg, pos, flags);
+        local_sort_bucket<K, NWAVES, KPT, MAPPED>(buf, src16, start, bucket, start, bstart[bucket + 1] - start, err, neg, pos, flags);
         return;
     }
     const uint32_t todo = *list_count;
@@ -1761,7 +2048,8 @@ __global__ __launch_bounds__(NWAVES * 64, (sizeof(K) <= 4 ? 2 : 1) * NWAVES / 4)
     for (uint32_t e = blockIdx.x; e < todo; e += gridDim.x) {
         const uint32_t bucket = list[e];
         const uint32_t start = bstart[bucket];
-        local_sort_bucket<K, NWAVES, KPT, MAPPED>(buf, src16, bucket, start, bstart[bucket + 1] - start, err, neg, pos, flags);
+        const uint32_t cnt = slot_count ? slot_count[bucket] : bstart[bucket + 1] - start;
+        local_sort_bucket<K, NWAVES, KPT, MAPPED>(buf, src16, slot_count ? bucket * slot_cap : start, bucket, start, cnt, err, neg, pos, flags);
         __syncthreads();  // the next bucket reuses the LDS
     }
 }
@@ -1794,7 +2082,8 @@ template <int BLOCK, bool MAPPED, bool FROM16>
 __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 8 : 6) void local_count_sort_kernel(
     uint32_t* __restrict__ buf_keys, uint32_t* __restrict__ buf_tmp, const uint16_t* __restrict__ src16, const uint32_t* __restrict__ bstart,
     const Plan* __restrict__ plan, uint32_t* __restrict__ err, uint32_t neg, uint32_t pos, uint32_t* __restrict__ list,
-    uint32_t* __restrict__ list_count) {
+    uint32_t* __restrict__ list_count, const uint32_t* __restrict__ slot_count /* ROUTE_ATOMIC: bucket b's halves lie in slot b (slot_cap
+    entries) of src16 and number slot_count[b]; NULL: they lie at their final place, bstart */, uint32_t slot_cap) {
     constexpr int MAXR = (COUNT_TILE + BLOCK - 1) / BLOCK;
     constexpr int VPT = H16_BINS / BLOCK, WPT = VPT / 8;  // values / counter words per thread
     constexpr int LOG_VPT = BLOCK == 1024 ? 6 : (BLOCK == 512 ? 7 : 8);
@@ -1802,12 +2091,13 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 8 : 6) void local_count_sort
     if (!plan->local_sort) return;
     uint32_t* __restrict__ buf = plan->result_in_tmp ? buf_tmp : buf_keys;
     const uint32_t bucket = blockIdx.x;
-    const uint32_t start = bstart[bucket], cnt = bstart[bucket + 1] - start;
+    const uint32_t start = bstart[bucket], cnt = slot_count ? slot_count[bucket] : bstart[bucket + 1] - start;
+    const uint32_t soff = slot_count ? bucket * slot_cap : start;  // where the bucket's keys lie now
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (cnt <= 1) {
         if constexpr (FROM16) {  // the key exists only as its low half: put it back together
             if (cnt == 1 && tid == 0) {
-                const uint32_t m = (bucket << 16) | (uint32_t)src16[start];
+                const uint32_t m = (bucket << 16) | (uint32_t)src16[soff];
                 buf[start] = MAPPED ? unmap_key<uint32_t>(m, neg, pos) : m;
             }
         }
@@ -1827,9 +2117,9 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 8 : 6) void local_count_sort
 #pragma unroll
     for (int i = 0; i < MAXR; ++i) {
         const uint32_t idx = (uint32_t)tid + i * BLOCK;
-        const uint32_t at = start + (idx < cnt ? idx : cnt - 1);
-        if constexpr (FROM16) kv[i] = src16[at];
-        else kv[i] = buf[at];
+        const uint32_t at = idx < cnt ? idx : cnt - 1;
+        if constexpr (FROM16) kv[i] = src16[soff + at];
+        else kv[i] = buf[start + at];
     }
 #pragma unroll
     for (int k = 0; k < WPT; ++k) cnt4[k * BLOCK + tid] = 0;
@@ -2321,7 +2611,7 @@ __global__ __launch_bounds__(256) void stream_read_kernel(const uint4* __restric
 // Status rows of the levels only the LSD route uses: cleared after the route decision, and only if it fell that way
 __global__ __launch_bounds__(256) void clear_unless_hybrid_kernel(const Plan* __restrict__ plan, uint4* __restrict__ a, uint64_t na, uint4* __restrict__ b,
                                                                   uint64_t nb) {
-    if (plan->route == ROUTE_HYBRID) return;
+    if (plan->route != ROUTE_LSD) return;
     const uint64_t stride = (uint64_t)gridDim.x * 256;
     const uint4 z = {0, 0, 0, 0};
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < na; i += stride) a[i] = z;
@@ -2456,6 +2746,7 @@ struct Tuning {
     bool halves = true;                 // 4-byte keys: pass L-1 hands K4 the low halves only (16-bit array in the workspace)
     bool presample = true;              // a 65 536-key sample before K1h: gross skew goes straight to the LSD route
     bool wide2 = true;                  // 8-byte keys: K4 as two 512-thread blocks per CU (false: one 1024-thread block)
+    bool atomic_route = false;          // 4-byte keys: try ROUTE_ATOMIC (no counting read) before anything else
     uint64_t hybrid_min_len = 1ull << 28;  // below this the buckets are too small for one workgroup each to pay off
 };
 uint32_t g_ablate = 0;  // only ever set by the RDST_EXPERIMENTS build
@@ -2500,7 +2791,8 @@ struct Layout {
     uint32_t levels, tile, status_bytes;  // status_bytes: 4 or 8 per word
     uint64_t tiles;
     size_t off_err, off_tickets, off_plan, off_hpos, off_hpair, off_h16, off_hpos16, off_status, off_status_near, zero_bytes, off_hist, off_base,
-        off_cbase, off_chains, off_bstart, off_fblist, off_halves, total;
+        off_cbase, off_chains, off_bstart, off_fblist, off_halves, off_cursor_a, off_cursor_b, off_msd_a, total;
+    uint32_t msd_cap_a;  // ROUTE_ATOMIC: keys an area of pass A holds
 };
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -2510,7 +2802,8 @@ int tile_keys(int cfg, uint32_t elem_bytes) {
     return p.nwaves * 64 * kpt_for(p.kpt8, elem_bytes);
 }
 
-Layout make_layout(uint64_t n, uint32_t elem_bytes, uint32_t levels, int cfg, uint32_t tile_override = 0, bool want_halves = false) {
+Layout make_layout(uint64_t n, uint32_t elem_bytes, uint32_t levels, int cfg, uint32_t tile_override = 0, bool want_halves = false,
+                   bool want_msd = false) {
     Layout L{};
     L.levels = levels;
     L.tile = tile_override ? tile_override : (uint32_t)tile_keys(cfg, elem_bytes);
@@ -2523,6 +2816,8 @@ Layout make_layout(uint64_t n, uint32_t elem_bytes, uint32_t levels, int cfg, ui
     L.off_plan = o; o += align_up(sizeof(Plan), 16);
     L.off_hpos = o; o += sizeof(uint64_t) * (size_t)levels * CHAINS * RADIX;
     L.off_hpair = o; o += sizeof(uint64_t) * (size_t)levels * CHAINS * RADIX;
+    L.off_cursor_a = o; o += sizeof(uint32_t) * RADIX * MSD_SLICES;         // ROUTE_ATOMIC: claim counters of pass A (digit x slice) ...
+    L.off_cursor_b = o; o += sizeof(uint32_t) * (size_t)H16_BINS;           // ... and of pass B (one per bucket)
     L.off_h16 = o; o += sizeof(uint32_t) * (size_t)H16_BINS;              // hybrid route: bucket counts (K1h)
     L.off_hpos16 = o; o += sizeof(uint64_t) * (size_t)CHAINS * RADIX;     // and its level L-2 counts per position range
     L.off_status = o; o += (size_t)L.status_bytes * levels * L.tiles * RADIX;
@@ -2537,7 +2832,16 @@ Layout make_layout(uint64_t n, uint32_t elem_bytes, uint32_t levels, int cfg, ui
     L.off_fblist = o; o += sizeof(uint32_t) * (size_t)H16_BINS;           // buckets left to the generic local sort (count: header word 3)
     o = align_up(o, 256);
     L.off_halves = o;                                                       // hybrid route, 4-byte keys: low halves between pass L-1 and K4
-    if (want_halves) o += align_up(sizeof(uint16_t) * n, 256);
+    if (want_halves && !want_msd) o += align_up(sizeof(uint16_t) * n, 256);
+    if (want_msd) o += align_up(sizeof(uint16_t) * (size_t)H16_BINS * local_tile(4), 256);  // ROUTE_ATOMIC: 65 536 slots of one K4 tile
+    L.off_msd_a = o;
+    L.msd_cap_a = 0;
+    if (want_msd) {  // areas of pass A: mean + max(1 %, 8 sigma) keys, whole 64s
+        const double mean = (double)n / (RADIX * MSD_SLICES);
+        const double slack = mean * 0.01 > 8.0 * __builtin_sqrt(mean) ? mean * 0.01 : 8.0 * __builtin_sqrt(mean);
+        L.msd_cap_a = (uint32_t)(((uint64_t)(mean + slack) + 64) / 64 * 64);
+        o += align_up(sizeof(uint32_t) * (size_t)L.msd_cap_a * RADIX * MSD_SLICES, 256);
+    }
     L.total = align_up(o, 256);
     return L;
 }
@@ -2610,6 +2914,13 @@ int prof_mark(DeviceState& D, hipStream_t s, uint32_t kind = 0) {
     return RDST_OK;
 }
 
+// ROUTE_ATOMIC: 4-byte keys, and a length at which a uniform bucket (n / 65 536 keys) stays 8 sigma below the K4 tile
+bool atomic_eligible(uint64_t n, size_t key_bytes, int cfg) {
+    if (!g_tuning.hybrid || !g_tuning.atomic_route || key_bytes != 4 || cfg != 4 || n < g_tuning.hybrid_min_len || n >= (1ull << 30)) return false;
+    const double mean = (double)n / H16_BINS;
+    return mean + 8.0 * __builtin_sqrt(mean) <= (double)local_tile(4);
+}
+
 bool hybrid_eligible(uint64_t n, size_t key_bytes) {
     return g_tuning.hybrid && (key_bytes == 4 || key_bytes == 8) && n >= g_tuning.hybrid_min_len &&
            n <= (uint64_t)H16_BINS * local_tile(key_bytes) && n < (1ull << 32);
@@ -2665,24 +2976,31 @@ int launch_hist(const K* keys, uint64_t n, uint32_t blocks, KeyMap km, unsigned 
     return launch_hist_v<K, LEVELS, 1, false>(keys, n, blocks, km, hpos, hpair, inversion, plan, s, piece_out, base_level);
 }
 
+// the look before K1h / before the atomic route's first pass
+template <typename K>
+int launch_presample(const K* keys, uint64_t n, KeyMap km, Plan* plan, hipStream_t s) {
+    if (!g_tuning.presample || n < PRESAMPLE_MIN_LEN) return RDST_OK;
+    const bool mapped = km.neg != 0 || km.pos != 0;
+    const uint32_t limit = 12u + (uint32_t)(4ull * (uint64_t)local_tile(sizeof(K)) * PRESAMPLE_KEYS / n);
+    constexpr size_t plds = presample_lds_bytes();
+    if (mapped) {
+        if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&presample_kernel<K, true>), plds)) return rc;
+        hipLaunchKernelGGL((presample_kernel<K, true>), dim3(1), dim3(1024), plds, s, keys, n, (K)km.neg, (K)km.pos, plan, limit);
+    } else {
+        if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&presample_kernel<K, false>), plds)) return rc;
+        hipLaunchKernelGGL((presample_kernel<K, false>), dim3(1), dim3(1024), plds, s, keys, n, (K)km.neg, (K)km.pos, plan, limit);
+    }
+    HIP_TRY(hipGetLastError());
+    return RDST_OK;
+}
+
 // K1h: the hybrid route's 65 536-bin count (same grid and pieces as K1)
 template <typename K>
 int launch_hist16(const K* keys, uint64_t n, uint32_t blocks, KeyMap km, uint32_t* h16, unsigned long long* hpos16, uint32_t* inversion,
                   uint32_t* overflow, Plan* plan, hipStream_t s) {
     const bool aligned = (reinterpret_cast<uintptr_t>(keys) & 15u) == 0;
     const bool mapped = km.neg != 0 || km.pos != 0;
-    if (g_tuning.presample && n >= PRESAMPLE_MIN_LEN) {
-        const uint32_t limit = 12u + (uint32_t)(4ull * (uint64_t)local_tile(sizeof(K)) * PRESAMPLE_KEYS / n);
-        constexpr size_t plds = presample_lds_bytes();
-        if (mapped) {
-            if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&presample_kernel<K, true>), plds)) return rc;
-            hipLaunchKernelGGL((presample_kernel<K, true>), dim3(1), dim3(1024), plds, s, keys, n, (K)km.neg, (K)km.pos, plan, limit);
-        } else {
-            if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&presample_kernel<K, false>), plds)) return rc;
-            hipLaunchKernelGGL((presample_kernel<K, false>), dim3(1), dim3(1024), plds, s, keys, n, (K)km.neg, (K)km.pos, plan, limit);
-        }
-        HIP_TRY(hipGetLastError());
-    }
+    if (int rc = launch_presample<K>(keys, n, km, plan, s)) return rc;
     constexpr int V = 16 / sizeof(K);
     constexpr size_t lds = (size_t)H16_WORDS * sizeof(uint32_t);
 #define RDST_H16(VEC, MAPPED)                                                                                              \
@@ -2706,7 +3024,8 @@ constexpr int COUNT_THREADS = RDST_COUNT_THREADS;
 // over the (normally empty) list of buckets it could not take; 8-byte keys: the generic one over all buckets.
 template <typename K>
 int launch_local_sort(K* keys, K* tmp, const uint32_t* bstart, const Plan* plan, uint32_t* err, KeyMap km, uint32_t* list,
-                      uint32_t* list_count, const uint16_t* src16, int cus, hipStream_t s) {
+                      uint32_t* list_count, const uint16_t* src16, int cus, hipStream_t s, const uint32_t* slot_count = nullptr,
+                      uint32_t slot_cap = 0) {
     constexpr int NW = local_waves(sizeof(K)), KPT = local_kpt(sizeof(K));
     constexpr size_t lds = local_lds_bytes(sizeof(K));
     const bool mapped = km.neg != 0 || km.pos != 0;
@@ -2719,7 +3038,7 @@ int launch_local_sort(K* keys, K* tmp, const uint32_t* bstart, const Plan* plan,
     do {                                                                                                                             \
         if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_count_sort_kernel<COUNT_THREADS, MAPPED, FROM16>), clds)) return rc; \
         hipLaunchKernelGGL((local_count_sort_kernel<COUNT_THREADS, MAPPED, FROM16>), dim3(H16_BINS), dim3(COUNT_THREADS), clds, s, keys, tmp, \
-                           src16, bstart, plan, err, (uint32_t)km.neg, (uint32_t)km.pos, list, list_count);                       \
+                           src16, bstart, plan, err, (uint32_t)km.neg, (uint32_t)km.pos, list, list_count, slot_count, slot_cap); \
     } while (0)
             if (src16) { if (mapped) RDST_COUNT(true, true); else RDST_COUNT(false, true); }
             else { if (mapped) RDST_COUNT(true, false); else RDST_COUNT(false, false); }
@@ -2755,10 +3074,10 @@ int launch_local_sort(K* keys, K* tmp, const uint32_t* bstart, const Plan* plan,
     const uint32_t* wl = listed ? list : nullptr;
     if (mapped) {
         if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_sort_kernel<K, NW, KPT, true>), lds)) return rc;
-        hipLaunchKernelGGL((local_sort_kernel<K, NW, KPT, true>), grid, dim3(NW * 64), lds, s, keys, tmp, bstart, plan, err, (K)km.neg, (K)km.pos, flags, wl, list_count, src16);
+        hipLaunchKernelGGL((local_sort_kernel<K, NW, KPT, true>), grid, dim3(NW * 64), lds, s, keys, tmp, bstart, plan, err, (K)km.neg, (K)km.pos, flags, wl, list_count, src16, slot_count, slot_cap);
     } else {
         if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_sort_kernel<K, NW, KPT, false>), lds)) return rc;
-        hipLaunchKernelGGL((local_sort_kernel<K, NW, KPT, false>), grid, dim3(NW * 64), lds, s, keys, tmp, bstart, plan, err, (K)km.neg, (K)km.pos, flags, wl, list_count, src16);
+        hipLaunchKernelGGL((local_sort_kernel<K, NW, KPT, false>), grid, dim3(NW * 64), lds, s, keys, tmp, bstart, plan, err, (K)km.neg, (K)km.pos, flags, wl, list_count, src16, slot_count, slot_cap);
     }
     HIP_TRY(hipGetLastError());
     return RDST_OK;
@@ -2889,9 +3208,11 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     // Hybrid route (whole sorts of 4- and 8-byte keys, long enough that a bucket is worth a workgroup, short
     // enough that 65 536 tiles can hold it): K1h counts the buckets, route_kernel decides.  If it says LSD,
     // K1 runs as ever (the slice is then read twice for counting); if it says hybrid, K1 returns at once.
-    const bool try_hybrid = !HAS_V && hybrid_eligible(n, sizeof(K)) && level_lo == 0 && level_hi == (uint32_t)LEVELS && allow_skip && copy_back;
+    const bool whole_sort = !HAS_V && level_lo == 0 && level_hi == (uint32_t)LEVELS && allow_skip && copy_back;
+    const bool try_atomic = whole_sort && atomic_eligible(n, sizeof(K), cfg);  // (its fallback is the LSD route: K1h is not tried then)
+    const bool try_hybrid = whole_sort && !try_atomic && hybrid_eligible(n, sizeof(K));
     const bool halves = try_hybrid && g_tuning.halves && g_tuning.count_sort && halves_possible<K>(cfg, n);
-    const Layout L = make_layout(n, sizeof(K), LEVELS, cfg, HAS_V ? PAIR_WAVES * 64 * pair_kpt(sizeof(K), ValBytes<V>::value) : 0, halves);
+    const Layout L = make_layout(n, sizeof(K), LEVELS, cfg, HAS_V ? PAIR_WAVES * 64 * pair_kpt(sizeof(K), ValBytes<V>::value) : 0, halves, try_atomic);
     if (L.tiles >= (1ull << 31)) return fail(RDST_ERR_ARG, "len too large for one launch");
     rc = ensure_workspace(*D, L.total);
     if (rc) return rc;
@@ -2909,7 +3230,9 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     // kernel behind the route decision (1 B u32: 0.07 ms of clearing -> half)
     const size_t level_rows = (size_t)L.status_bytes * L.tiles * RADIX;  // one level, one copy
     const bool split_clear = try_hybrid && LEVELS > 2;
-    if (split_clear) {
+    if (try_atomic) {
+        HIP_TRY(hipMemsetAsync(ws, 0, L.off_status, s));  // the status rows are the LSD route's: cleared behind the route decision, if it fell that way
+    } else if (split_clear) {
         HIP_TRY(hipMemsetAsync(ws, 0, L.off_status, s));
         HIP_TRY(hipMemsetAsync(ws + L.off_status + level_rows * (LEVELS - 2), 0, level_rows * 2, s));
         HIP_TRY(hipMemsetAsync(ws + L.off_status_near + level_rows * (LEVELS - 2), 0, level_rows * 2, s));
@@ -2943,6 +3266,59 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     const bool pair = g_tuning.chains && LEVELS >= 2 && level_hi > level_lo + 1;
     unsigned long long* hpair = reinterpret_cast<unsigned long long*>(ws + L.off_hpair);
     Plan* plan = reinterpret_cast<Plan*>(ws + L.off_plan);
+    if constexpr (!HAS_V && sizeof(K) == 4) {
+        if (try_atomic) {
+            constexpr int KPT = 22, NW = 12, TILE = NW * 64 * KPT;
+            constexpr size_t mlds = (size_t)NW * 1024 + 1024 + 64 + sizeof(uint32_t) * TILE;
+            uint32_t* overflow = reinterpret_cast<uint32_t*>(ws + L.off_err) + 4;
+            uint32_t* cursor_a = reinterpret_cast<uint32_t*>(ws + L.off_cursor_a);
+            uint32_t* cursor_b = reinterpret_cast<uint32_t*>(ws + L.off_cursor_b);
+            uint32_t* area_a = reinterpret_cast<uint32_t*>(ws + L.off_msd_a);
+            uint16_t* slots = reinterpret_cast<uint16_t*>(ws + L.off_halves);
+            const bool mapped = km.neg != 0 || km.pos != 0;
+            if ((rc = launch_presample<K>(keys, n, km, plan, s))) return rc;
+            const uint32_t tiles_a = (uint32_t)((n + TILE - 1) / TILE);
+            const uint32_t tpa = (L.msd_cap_a + TILE - 1) / TILE;
+#define RDST_MSD(MAPPED, HALVES, GRID, ...)                                                                                          \
+    do {                                                                                                                             \
+        if ((rc = ensure_lds_attr(reinterpret_cast<const void*>(&msd_scatter_kernel<KPT, NW, MAPPED, HALVES>), mlds))) return rc;    \
+        hipLaunchKernelGGL((msd_scatter_kernel<KPT, NW, MAPPED, HALVES>), dim3(GRID), dim3(NW * 64), mlds, s, __VA_ARGS__);          \
+    } while (0)
+            // pass A: the slice, by its top byte, into 256 x 8 areas
+            if (mapped) RDST_MSD(true, false, tiles_a, reinterpret_cast<const uint32_t*>(keys), nullptr, n, 0u, tiles_a, area_a, nullptr, cursor_a, L.msd_cap_a, 24, plan, overflow, inversion, (uint32_t)km.neg, (uint32_t)km.pos);
+            else RDST_MSD(false, false, tiles_a, reinterpret_cast<const uint32_t*>(keys), nullptr, n, 0u, tiles_a, area_a, nullptr, cursor_a, L.msd_cap_a, 24, plan, overflow, inversion, (uint32_t)km.neg, (uint32_t)km.pos);
+            HIP_TRY(hipGetLastError());
+            if ((rc = prof_mark(*D, s, RDST_STAGE_MSD_A))) return rc;
+            // pass B: every area, by the second byte, into the slot of its bucket (low halves)
+            const uint32_t grid_b = (uint32_t)(RADIX * MSD_SLICES) * tpa;
+            if (mapped) RDST_MSD(true, true, grid_b, area_a, cursor_a, 0ull, L.msd_cap_a, tpa, nullptr, slots, cursor_b, (uint32_t)local_tile(4), 16, plan, overflow, inversion, (uint32_t)km.neg, (uint32_t)km.pos);
+            else RDST_MSD(false, true, grid_b, area_a, cursor_a, 0ull, L.msd_cap_a, tpa, nullptr, slots, cursor_b, (uint32_t)local_tile(4), 16, plan, overflow, inversion, (uint32_t)km.neg, (uint32_t)km.pos);
+#undef RDST_MSD
+            HIP_TRY(hipGetLastError());
+            if ((rc = prof_mark(*D, s, RDST_STAGE_MSD_B))) return rc;
+            MsdFinishArgs fa{};
+            fa.cursor_b = cursor_b;
+            fa.overflow = overflow;
+            fa.inversion = inversion;
+            fa.bstart = reinterpret_cast<uint32_t*>(ws + L.off_bstart);
+            fa.plan = plan;
+            fa.n = n;
+            fa.allow_skip = allow_skip ? 1u : 0u;
+            hipLaunchKernelGGL(msd_finish_kernel, dim3(1), dim3(1024), 0, s, fa);
+            HIP_TRY(hipGetLastError());
+            if ((rc = prof_mark(*D, s, RDST_STAGE_ROUTE))) return rc;
+            rc = launch_local_sort<K>(keys, tmp, reinterpret_cast<const uint32_t*>(ws + L.off_bstart), plan, D->err_dev, km,
+                                      reinterpret_cast<uint32_t*>(ws + L.off_fblist), reinterpret_cast<uint32_t*>(ws + L.off_err) + 3, slots,
+                                      D->cus, s, cursor_b, (uint32_t)local_tile(4));
+            if (rc) return rc;
+            if ((rc = prof_mark(*D, s, RDST_STAGE_LOCAL))) return rc;
+            // the LSD route's status rows, if the route fell that way
+            const uint64_t vecs = level_rows * LEVELS / 16;
+            hipLaunchKernelGGL(clear_unless_hybrid_kernel, dim3((uint32_t)D->cus * 4), dim3(256), 0, s, plan, reinterpret_cast<uint4*>(ws + L.off_status),
+                               vecs, reinterpret_cast<uint4*>(ws + L.off_status_near), vecs);
+            HIP_TRY(hipGetLastError());
+        }
+    }
     if constexpr (!HAS_V && (sizeof(K) == 4 || sizeof(K) == 8)) {
         if (try_hybrid) {
             uint32_t* overflow = reinterpret_cast<uint32_t*>(ws + L.off_err) + 2;
@@ -2977,7 +3353,7 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     }
     // a single pass (the parity hook, the sharded route's split) counts its own level only: one LDS atomic per key
     if (LEVELS > 1 && level_hi == level_lo + 1) rc = launch_hist<K, 1>(keys, n, (uint32_t)blocks, km, hpos, hpair, false, inversion, nullptr, s, &piece, (int)level_lo);
-    else rc = launch_hist<K, LEVELS>(keys, n, (uint32_t)blocks, km, hpos, hpair, pair, inversion, try_hybrid ? plan : nullptr, s, &piece);
+    else rc = launch_hist<K, LEVELS>(keys, n, (uint32_t)blocks, km, hpos, hpair, pair, inversion, (try_hybrid || try_atomic) ? plan : nullptr, s, &piece);
     if (rc) return rc;
     if ((rc = prof_mark(*D, s, RDST_STAGE_HIST))) return rc;
     ScanArgs sa{};
@@ -3274,6 +3650,7 @@ int rdst_hip_set_hybrid(int enabled, uint64_t min_len) {
     g_tuning.halves = enabled != 3;      // 3: counting K4 reading whole keys (no 16-bit hand-off) (A/B, tests)
     g_tuning.presample = enabled != 5;   // 5: no sample before K1h: every hybrid-eligible sort counts all its keys' prefixes first (tests)
     g_tuning.wide2 = enabled != 6;       // 6: 8-byte keys with the one-block-per-CU form of K4 (A/B, tests)
+    g_tuning.atomic_route = enabled == 7;  // 7: ROUTE_ATOMIC for 4-byte keys
     g_tuning.hybrid_min_len = min_len ? min_len : (1ull << 28);
     return RDST_OK;
 }
@@ -3430,8 +3807,9 @@ uint64_t rdst_hip_workspace_bytes(uint64_t len, uint32_t elem_bytes) {
     if (elem_bytes != 1 && elem_bytes != 2 && elem_bytes != 4 && elem_bytes != 8 && elem_bytes != 16) return 0;
     int cfg = g_tuning.pass_cfg;
     if (cfg < 0 || cfg >= kNumPassCfgs) cfg = default_cfg(elem_bytes, len, true);  // the shape with the smaller tiles: an upper bound for every key kind
-    const bool halves = elem_bytes == 4 && hybrid_eligible(len, 4) && g_tuning.halves && g_tuning.count_sort && cfg == 4 && len < (1ull << 30);
-    return make_layout(len, elem_bytes, elem_bytes, cfg, 0, halves).total;
+    const bool msd = atomic_eligible(len, elem_bytes, cfg);
+    const bool halves = !msd && elem_bytes == 4 && hybrid_eligible(len, 4) && g_tuning.halves && g_tuning.count_sort && cfg == 4 && len < (1ull << 30);
+    return make_layout(len, elem_bytes, elem_bytes, cfg, 0, halves, msd).total;
 }
 
 int rdst_hip_sort_device(void* dev_keys, void* dev_tmp, uint64_t len, uint32_t elem_bytes, rdst_key_kind kind,

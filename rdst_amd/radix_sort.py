@@ -430,7 +430,7 @@ def profile_runs() -> int:
     return int(_lib.load().rdst_hip_profile_runs())
 
 
-STAGE_NAMES = {1: "clear", 2: "histogram", 3: "scan", 4: "pass", 5: "copy_back", 6: "histogram16", 7: "route", 8: "local_sort"}
+STAGE_NAMES = {1: "clear", 2: "histogram", 3: "scan", 4: "pass", 5: "copy_back", 6: "histogram16", 7: "route", 8: "local_sort", 10: "msd_pass_a", 11: "msd_pass_b"}
 
 
 def profile_run(run: int, levels: int):
@@ -464,7 +464,7 @@ def profile_run(run: int, levels: int):
 def set_hybrid(enabled=True, min_len=0):
     """Route choice knob (rdst_hip_set_hybrid): consider the hybrid route for sorts of at least `min_len` keys
     (0 = built-in threshold).  enabled == 2: the hybrid route with the generic ranked local sort for 4-byte keys too; 3: counting local sort fed with whole keys (no 16-bit hand-off)."""
-    _lib.check(_lib.load().rdst_hip_set_hybrid(int(enabled) if enabled in (2, 3, 5, 6) else int(bool(enabled)), int(min_len)))
+    _lib.check(_lib.load().rdst_hip_set_hybrid(int(enabled) if enabled in (2, 3, 5, 6, 7) else int(bool(enabled)), int(min_len)))
 
 
 def last_route(device=None) -> str:
@@ -474,7 +474,7 @@ def last_route(device=None) -> str:
     r = ctypes.c_uint32(0)
     with torch.cuda.device(device):
         _lib.check(lib.rdst_hip_last_route(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), ctypes.byref(r)))
-    return "hybrid" if r.value == 1 else "lsd"
+    return {1: "hybrid", 2: "atomic"}.get(r.value, "lsd")
 
 
 def last_profile(levels: int):
