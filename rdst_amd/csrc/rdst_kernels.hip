@@ -88,13 +88,13 @@ constexpr uint32_t ERR_LOCAL_OVERFLOW = 4;  // a bucket of the hybrid route larg
 //                 of 136).  Taken when every bucket fits K4's tile; anything else goes the LSD way.
 //   ROUTE_ATOMIC  (4-byte keys) the hybrid route without its counting read.  An MSD pass needs no stable order and no exact
 //                 global offsets up front, only ROOM: pass A scatters by the top byte into 256 x 8 over-provisioned areas
-//                 (digit x XCD slice) of the workspace, a tile claiming its space per digit with ONE returning global
+//                 (XCD slice x digit) of the workspace, a tile claiming its space per digit with ONE returning global
 //                 atomic where K3 walks back over its predecessors; pass B scatters every area by the second byte into
 //                 65 536 slots of one K4 tile each (low halves only); K4 sorts each slot's bucket to its exact place
 //                 (exclusive scan of the 65 536 claim counters).  8 + 6 + 6 = 20 bytes per key.  Uniform keys never
 //                 overflow an area (capacity = mean + max(1 %, 8 sigma)); anything that does takes the LSD route.
 constexpr uint32_t ROUTE_LSD = 0, ROUTE_HYBRID = 1, ROUTE_ATOMIC = 2;
-constexpr int MSD_SLICES = 8;  // areas per top digit in pass A: blocks b and b + 8 share an XCD, so a digit's 8 frontiers stay with one L2 each
+constexpr int MSD_SLICES = 8;  // areas per top digit in pass A: one per XCD, claimed with L2-local atomics (msd_scatter_kernel)
 constexpr int H16_BINS = 65536;
 
 struct Plan {
@@ -1503,6 +1503,7 @@ template <int KPT, int NWAVES, bool MAPPED, bool HALVES>
 __global__ __launch_bounds__(NWAVES * 64, (2 * NWAVES + 3) / 4) void msd_scatter_kernel(
     const uint32_t* __restrict__ src, const uint32_t* __restrict__ area_count /* nullable: one area of n keys */, uint64_t n, uint32_t area_cap,
     uint32_t tiles_per_area, uint32_t* __restrict__ dst, uint16_t* __restrict__ dst16, uint32_t* __restrict__ cursor, uint32_t dst_cap, int shift,
+    uint32_t slices /* areas per top digit (pass A: of the destination, pass B: of the source) */,
     const Plan* __restrict__ plan, uint32_t* __restrict__ overflow, uint32_t* __restrict__ inversion /* pass A sets it; pass B reads it */,
     uint32_t neg, uint32_t pos) {
     using K = uint32_t;
@@ -1518,6 +1519,8 @@ __global__ __launch_bounds__(NWAVES * 64, (2 * NWAVES + 3) / 4) void msd_scatter
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t area = blockIdx.x / tiles_per_area, j = blockIdx.x % tiles_per_area;
     const uint64_t acount = area_count ? (uint64_t)area_count[area] : n;
+    // XCC_ID (hardware register 20, 4 bits): which of the 8 XCDs runs this workgroup
+    const uint32_t my_slice = slices > 1 ? ((uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) % slices) : 0u;
     const uint64_t tile_off = (uint64_t)j * TILE;
     if (tile_off >= acount) return;
     const uint32_t valid = acount - tile_off < (uint64_t)TILE ? (uint32_t)(acount - tile_off) : (uint32_t)TILE;
@@ -1561,7 +1564,8 @@ __global__ __launch_bounds__(NWAVES * 64, (2 * NWAVES + 3) / 4) void msd_scatter
             if (lane == 0) before = i == 0 ? edge : (K)__builtin_amdgcn_readlane((int)mk[i > 0 ? i - 1 : 0], 63);
             inv |= before > mk[i];  // (padding is the largest key and sits at the end: it never counts as an inversion)
         }
-        if (__builtin_amdgcn_ballot_w64(inv) != 0 && lane == 0) atomicOr(inversion, 1u);
+        // (one word for the whole grid: look before setting — 700 000 waves OR-ing the same word took 8 ms, ~88 atomics per us)
+        if (__builtin_amdgcn_ballot_w64(inv) != 0 && lane == 0 && ld_relaxed<uint32_t>(inversion) == 0) atomicOr(inversion, 1u);
     }
     __builtin_amdgcn_s_setprio(0);
     uint32_t* wh = wave_hist + wave * RADIX;
@@ -1635,10 +1639,18 @@ __global__ __launch_bounds__(NWAVES * 64, (2 * NWAVES + 3) / 4) void msd_scatter
             run += cw[w];
         }
         // claim the run's space: one returning atomic per digit and tile
-        const uint32_t where = HALVES ? (area / MSD_SLICES) * RADIX + (uint32_t)tid : (uint32_t)tid * MSD_SLICES + (blockIdx.x % MSD_SLICES);
+        // pass A: area (slice, digit), slice = the XCD this block REALLY runs on (hardware register, not the dispatch pattern);
+        // pass B: slot (top digit of the source area, digit)
+        const uint32_t where = HALVES ? (area % RADIX) * RADIX + (uint32_t)tid : my_slice * RADIX + (uint32_t)tid;
         uint32_t got = 0;
         if (pub) {
-            got = atomicAdd(&cursor[where], pub);
+            // Pass A has only 256 x 8 counters for ~59 000 tiles x 256 claims.  As device-scope atomics they execute at the memory
+            // side and serialise per counter at ~1 us each: 8.2 ms per pass.  A slice's counters are claimed by ONE XCD only (see
+            // my_slice), so workgroup scope is enough — such an atomic executes in that XCD's L2, atomically for all its CUs —
+            // and the kernel boundary writes the final counts back for pass B, which may run anywhere.  Each slice's 256 counters
+            // fill whole 128-byte lines of their own: no line is shared between XCDs.
+            if constexpr (HALVES) got = atomicAdd(&cursor[where], pub);
+            else got = __hip_atomic_fetch_add(&cursor[where], pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (got + pub > dst_cap) {  // no room: give the route up, store nothing of this tile
                 atomicOr(overflow, 1u);
                 s_misc[1] = 1;
@@ -2792,7 +2804,7 @@ struct Layout {
     uint64_t tiles;
     size_t off_err, off_tickets, off_plan, off_hpos, off_hpair, off_h16, off_hpos16, off_status, off_status_near, zero_bytes, off_hist, off_base,
         off_cbase, off_chains, off_bstart, off_fblist, off_halves, off_cursor_a, off_cursor_b, off_msd_a, total;
-    uint32_t msd_cap_a;  // ROUTE_ATOMIC: keys an area of pass A holds
+    uint32_t msd_cap_a, msd_slices;  // ROUTE_ATOMIC: keys an area of pass A holds; areas per top digit
 };
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -2816,7 +2828,8 @@ Layout make_layout(uint64_t n, uint32_t elem_bytes, uint32_t levels, int cfg, ui
     L.off_plan = o; o += align_up(sizeof(Plan), 16);
     L.off_hpos = o; o += sizeof(uint64_t) * (size_t)levels * CHAINS * RADIX;
     L.off_hpair = o; o += sizeof(uint64_t) * (size_t)levels * CHAINS * RADIX;
-    L.off_cursor_a = o; o += sizeof(uint32_t) * RADIX * MSD_SLICES;         // ROUTE_ATOMIC: claim counters of pass A (digit x slice) ...
+    o = align_up(o, 128);
+    L.off_cursor_a = o; o += sizeof(uint32_t) * RADIX * MSD_SLICES;         // ROUTE_ATOMIC: claim counters of pass A [slice][digit]: 8 lines per slice ...
     L.off_cursor_b = o; o += sizeof(uint32_t) * (size_t)H16_BINS;           // ... and of pass B (one per bucket)
     L.off_h16 = o; o += sizeof(uint32_t) * (size_t)H16_BINS;              // hybrid route: bucket counts (K1h)
     L.off_hpos16 = o; o += sizeof(uint64_t) * (size_t)CHAINS * RADIX;     // and its level L-2 counts per position range
@@ -2836,11 +2849,19 @@ Layout make_layout(uint64_t n, uint32_t elem_bytes, uint32_t levels, int cfg, ui
     if (want_msd) o += align_up(sizeof(uint16_t) * (size_t)H16_BINS * local_tile(4), 256);  // ROUTE_ATOMIC: 65 536 slots of one K4 tile
     L.off_msd_a = o;
     L.msd_cap_a = 0;
-    if (want_msd) {  // areas of pass A: mean + max(1 %, 8 sigma) keys, whole 64s
-        const double mean = (double)n / (RADIX * MSD_SLICES);
-        const double slack = mean * 0.01 > 8.0 * __builtin_sqrt(mean) ? mean * 0.01 : 8.0 * __builtin_sqrt(mean);
-        L.msd_cap_a = (uint32_t)(((uint64_t)(mean + slack) + 64) / 64 * 64);
-        o += align_up(sizeof(uint32_t) * (size_t)L.msd_cap_a * RADIX * MSD_SLICES, 256);
+    L.msd_slices = 1;
+    if (want_msd) {
+        // areas of pass A: tiles are dealt to the slices in turn, so a slice gets its share of the keys give or take a tile;
+        // capacity = mean + max(1 %, 8 sigma) + two tiles' worth of one digit, whole 64s.  Few tiles: one slice.
+        constexpr uint64_t TILE = 12 * 64 * 22;
+        const uint64_t tiles = (n + TILE - 1) / TILE;
+        L.msd_slices = tiles >= 64 * MSD_SLICES ? MSD_SLICES : 1;
+        const double mean = (double)n / (RADIX * L.msd_slices);
+        // (a slice = the tiles one XCD happens to run: the dispatcher deals workgroups evenly, an XCD that runs ahead takes a few
+        // more: 6 % of head room instead of the 1 % the key statistics alone would need)
+        const double slack = mean * 0.06 > 8.0 * __builtin_sqrt(mean) ? mean * 0.06 : 8.0 * __builtin_sqrt(mean);
+        L.msd_cap_a = (uint32_t)(((uint64_t)(mean + slack) + 2 * TILE / RADIX + 64) / 64 * 64);
+        o += align_up(sizeof(uint32_t) * (size_t)L.msd_cap_a * RADIX * L.msd_slices, 256);
     }
     L.total = align_up(o, 256);
     return L;
@@ -3285,14 +3306,14 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
         hipLaunchKernelGGL((msd_scatter_kernel<KPT, NW, MAPPED, HALVES>), dim3(GRID), dim3(NW * 64), mlds, s, __VA_ARGS__);          \
     } while (0)
             // pass A: the slice, by its top byte, into 256 x 8 areas
-            if (mapped) RDST_MSD(true, false, tiles_a, reinterpret_cast<const uint32_t*>(keys), nullptr, n, 0u, tiles_a, area_a, nullptr, cursor_a, L.msd_cap_a, 24, plan, overflow, inversion, (uint32_t)km.neg, (uint32_t)km.pos);
-            else RDST_MSD(false, false, tiles_a, reinterpret_cast<const uint32_t*>(keys), nullptr, n, 0u, tiles_a, area_a, nullptr, cursor_a, L.msd_cap_a, 24, plan, overflow, inversion, (uint32_t)km.neg, (uint32_t)km.pos);
+            if (mapped) RDST_MSD(true, false, tiles_a, reinterpret_cast<const uint32_t*>(keys), nullptr, n, 0u, tiles_a, area_a, nullptr, cursor_a, L.msd_cap_a, 24, L.msd_slices, plan, overflow, inversion, (uint32_t)km.neg, (uint32_t)km.pos);
+            else RDST_MSD(false, false, tiles_a, reinterpret_cast<const uint32_t*>(keys), nullptr, n, 0u, tiles_a, area_a, nullptr, cursor_a, L.msd_cap_a, 24, L.msd_slices, plan, overflow, inversion, (uint32_t)km.neg, (uint32_t)km.pos);
             HIP_TRY(hipGetLastError());
             if ((rc = prof_mark(*D, s, RDST_STAGE_MSD_A))) return rc;
             // pass B: every area, by the second byte, into the slot of its bucket (low halves)
-            const uint32_t grid_b = (uint32_t)(RADIX * MSD_SLICES) * tpa;
-            if (mapped) RDST_MSD(true, true, grid_b, area_a, cursor_a, 0ull, L.msd_cap_a, tpa, nullptr, slots, cursor_b, (uint32_t)local_tile(4), 16, plan, overflow, inversion, (uint32_t)km.neg, (uint32_t)km.pos);
-            else RDST_MSD(false, true, grid_b, area_a, cursor_a, 0ull, L.msd_cap_a, tpa, nullptr, slots, cursor_b, (uint32_t)local_tile(4), 16, plan, overflow, inversion, (uint32_t)km.neg, (uint32_t)km.pos);
+            const uint32_t grid_b = (uint32_t)RADIX * L.msd_slices * tpa;
+            if (mapped) RDST_MSD(true, true, grid_b, area_a, cursor_a, 0ull, L.msd_cap_a, tpa, nullptr, slots, cursor_b, (uint32_t)local_tile(4), 16, L.msd_slices, plan, overflow, inversion, (uint32_t)km.neg, (uint32_t)km.pos);
+            else RDST_MSD(false, true, grid_b, area_a, cursor_a, 0ull, L.msd_cap_a, tpa, nullptr, slots, cursor_b, (uint32_t)local_tile(4), 16, L.msd_slices, plan, overflow, inversion, (uint32_t)km.neg, (uint32_t)km.pos);
 #undef RDST_MSD
             HIP_TRY(hipGetLastError());
             if ((rc = prof_mark(*D, s, RDST_STAGE_MSD_B))) return rc;

@@ -143,7 +143,7 @@ def test_skewed_low_digits_inside_buckets(hybrid, dtype):
     for j, m in enumerate(masks):
         a = _with_prefixes(n, dtype, prefixes, seed=300 + j, low_mask=(m | (0xFFFF << (w - 16))))
         got, route = _sort(hybrid, a)
-        assert route == "hybrid", (dtype, hex(m))
+        assert _fast_route(hybrid, route, dtype, strict=False), (dtype, hex(m), route)
         assert same_bits(got, reference_sorted(a)), (dtype, hex(m))
     # every bucket already sorted / reverse sorted inside, buckets interleaved
     a = _with_prefixes(n, dtype, prefixes, seed=400)
