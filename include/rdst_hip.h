@@ -299,16 +299,17 @@ int rdst_hip_profile_run(int run, float* out_ms, uint32_t capacity, uint32_t* n_
  * inserts RDST_STAGE_HIST16 and RDST_STAGE_ROUTE after the clear and RDST_STAGE_LOCAL after the passes. */
 int rdst_hip_profile_run_stages(int run, uint32_t* stages_out, uint32_t capacity, uint32_t* n_out);
 
-/* Route choice.  Whole sorts of 4- and 8-byte keys with min_len <= len <= 65 536 tiles count the top 16 bits
- * of the keys first (K1h) and, when every one of the 65 536 buckets fits one tile of the in-LDS sort (K4),
- * take the hybrid route — the device form of rdst's own MSD-then-Lsb route at this size (SURVEY.md §3.1;
- * src/tuners/standard_tuner.rs:46-62 picks by length and counts, too).  enabled == 0: LSD route always;
- * enabled == 2: hybrid route, but 4-byte keys also use the generic ranked in-LDS sort instead of the
- * counting sort by value; enabled == 3: counting sort, but pass L-1 hands it whole keys instead of the 16-bit low
- * halves it normally leaves in the workspace; enabled == 5: no key sample before K1h; enabled == 6: 8-byte keys with the
- * one-block-per-CU form of the in-LDS sort (A/B and tests).
- * min_len == 0 keeps the built-in threshold (2^28).  Results are identical on either route.
- * Not part of the reference surface. */
+/* Route choice.  Whole sorts of 4- and 8-byte keys with min_len <= len (and short enough that a uniform bucket fits one
+ * tile of the in-LDS sort) try a route that moves fewer bytes than one scatter pass per level — the device form of rdst's
+ * own MSD-then-Lsb route at this size (src/tuners/standard_tuner.rs:46-62 picks by length and counts, too):
+ *   4-byte keys: the ATOMIC route — two MSD passes that claim space in over-provisioned areas with atomics (no counting
+ *   read at all), then the in-LDS sort of every bucket; if an area overflows (keys far from uniform) the LSD route runs;
+ *   8-byte keys: the HYBRID route — K1h counts the top 16 bits, two K3 passes, the in-LDS sort; LSD if a bucket is too large.
+ * enabled == 0: LSD route always; 1: the default above; 7: the hybrid (K1h) route for 4-byte keys too;
+ * 2 / 3 / 5 / 6: hybrid route for every width with one detail changed, for A/B runs and tests — 2: ranked in-LDS sort for
+ * 4-byte keys as well, 3: pass L-1 hands K4 whole keys instead of 16-bit halves, 5: no key sample before K1h, 6: 8-byte keys
+ * with the one-block-per-CU form of K4.  min_len == 0 keeps the built-in threshold (2^28).  Results are identical on every
+ * route.  Not part of the reference surface. */
 int rdst_hip_set_hybrid(int enabled, uint64_t min_len);
 
 /* Route the most recent sort enqueued by this library on the current device took (RDST_ROUTE_*).  Blocks on `stream`. */

@@ -94,7 +94,7 @@ constexpr uint32_t ERR_LOCAL_OVERFLOW = 4;  // a bucket of the hybrid route larg
 //                 (exclusive scan of the 65 536 claim counters).  8 + 6 + 6 = 20 bytes per key.  Uniform keys never
 //                 overflow an area (capacity = mean + max(1 %, 8 sigma)); anything that does takes the LSD route.
 constexpr uint32_t ROUTE_LSD = 0, ROUTE_HYBRID = 1, ROUTE_ATOMIC = 2;
-constexpr int MSD_SLICES = 8;  // areas per top digit in pass A: one per XCD, claimed with L2-local atomics (msd_scatter_kernel)
+constexpr int MSD_SLICES = 8;  // areas per top digit in pass A: blocks b and b + 8 share an XCD, so a digit's 8 frontiers stay with one L2 each
 constexpr int H16_BINS = 65536;
 
 struct Plan {
@@ -1016,7 +1016,12 @@ template <> struct ValBytes<NoVal> { static constexpr int value = 0; };
 // its top 16 bits (it lies in bucket b = [bstart[b], bstart[b+1])), so the pass stores only the low halves of the
 // MAPPED keys, as a 16-bit array `out16` in the workspace, and K4 reads those: 2 bytes per key less written, 2 less
 // read.  Decided at run time (the route is the device's choice): on the LSD route the same kernel stores whole keys.
-template <typename K, typename S, int KPT, int NWAVES, int STAGES, bool MAPPED, bool NARROW, typename V = NoVal, bool OUT16 = false>
+// PERSIST: the grid is two blocks per CU and a block takes tile after tile until the chains are dry, instead of one block
+// per tile.  Built for ONE use: the LSD fallback behind the atomic route (4-byte keys, shape 4) — on the good path those four
+// launches have nothing to do, and returning from ~59 000 workgroups costs 0.041 ms each where 512 cost 0.003; on the
+// fallback path the loop costs a few per cent of a pass (the compiler hoists lane-invariant addresses out of it and spills
+// 14 dwords per lane; an opaque thread id per iteration keeps it to that).
+template <typename K, typename S, int KPT, int NWAVES, int STAGES, bool MAPPED, bool NARROW, typename V = NoVal, bool OUT16 = false, bool PERSIST = false>
 __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8, NWAVES * 64 * KPT * ((int)sizeof(K) + ValBytes<V>::value) / STAGES) * NWAVES + 3) / 4) void onesweep_kernel(
     K* __restrict__ buf_keys, K* __restrict__ buf_tmp, V* __restrict__ buf_vals, V* __restrict__ buf_vtmp, uint16_t* __restrict__ out16, uint64_t n, int level,
     const uint64_t* __restrict__ cbase /* [CHAINS][256] of this level */, S* __restrict__ status /* [rows][256] of this level */,
@@ -1077,7 +1082,11 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8,
     // rows and its 256 scatter frontiers stay with one XCD's CUs — in ticket order, so a tile's
     // predecessors have always started; when that chain is handed out it tries the next ones
     // (segments of a skewed pass differ in length).  The grid has at least one block per tile.
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int tid_opaque = threadIdx.x;
+#pragma unroll 1
+    for (;;) {  // one tile (PERSIST: tile after tile; the ticket that finds every chain dry ends the block)
+    if constexpr (PERSIST) asm volatile("" : "+v"(tid_opaque));  // nothing derived from it is loop-invariant for the compiler
+    const int tid = tid_opaque, lane = tid & 63, wave = tid >> 6;
     // Wave priority: the phases that issue memory traffic (the tile's loads, the look-back, the
     // scatter) go ahead of other waves' arithmetic (counting, ranking), so the memory pipeline is fed
     // while the vector ALU works through the ranking of the CU's other block (A/B: pass 1.84 -> 1.75 ms);
@@ -1486,6 +1495,9 @@ ranked:
         rec[11] = blockIdx.x;
     }
 #endif
+    if constexpr (!PERSIST) break;
+    __syncthreads();  // the next tile reuses the LDS
+    }
 #undef RDST_ABL
 }
 
@@ -1519,8 +1531,6 @@ __global__ __launch_bounds__(NWAVES * 64, (2 * NWAVES + 3) / 4) void msd_scatter
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t area = blockIdx.x / tiles_per_area, j = blockIdx.x % tiles_per_area;
     const uint64_t acount = area_count ? (uint64_t)area_count[area] : n;
-    // XCC_ID (hardware register 20, 4 bits): which of the 8 XCDs runs this workgroup
-    const uint32_t my_slice = slices > 1 ? ((uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) % slices) : 0u;
     const uint64_t tile_off = (uint64_t)j * TILE;
     if (tile_off >= acount) return;
     const uint32_t valid = acount - tile_off < (uint64_t)TILE ? (uint32_t)(acount - tile_off) : (uint32_t)TILE;
@@ -1639,18 +1649,15 @@ __global__ __launch_bounds__(NWAVES * 64, (2 * NWAVES + 3) / 4) void msd_scatter
             run += cw[w];
         }
         // claim the run's space: one returning atomic per digit and tile
-        // pass A: area (slice, digit), slice = the XCD this block REALLY runs on (hardware register, not the dispatch pattern);
+        // pass A: area (slice, digit) — blocks b and b + 8 share an XCD, so a digit's 8 frontiers stay with one L2 each, and the
+        // tiles are dealt to the slices in turn: every slice gets its share of the keys give or take a tile;
         // pass B: slot (top digit of the source area, digit)
-        const uint32_t where = HALVES ? (area % RADIX) * RADIX + (uint32_t)tid : my_slice * RADIX + (uint32_t)tid;
+        const uint32_t where = HALVES ? (area % RADIX) * RADIX + (uint32_t)tid : (blockIdx.x % slices) * RADIX + (uint32_t)tid;
         uint32_t got = 0;
         if (pub) {
-            // Pass A has only 256 x 8 counters for ~59 000 tiles x 256 claims.  As device-scope atomics they execute at the memory
-            // side and serialise per counter at ~1 us each: 8.2 ms per pass.  A slice's counters are claimed by ONE XCD only (see
-            // my_slice), so workgroup scope is enough — such an atomic executes in that XCD's L2, atomically for all its CUs —
-            // and the kernel boundary writes the final counts back for pass B, which may run anywhere.  Each slice's 256 counters
-            // fill whole 128-byte lines of their own: no line is shared between XCDs.
-            if constexpr (HALVES) got = atomicAdd(&cursor[where], pub);
-            else got = __hip_atomic_fetch_add(&cursor[where], pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // (Pass A has only 256 x 8 counters for ~59 000 tiles x 256 claims.  Measured: device-scope claims cost the pass nothing —
+            // 1.555 ms against 1.554 with XCD-local workgroup-scope claims on per-XCD counters.)
+            got = atomicAdd(&cursor[where], pub);
             if (got + pub > dst_cap) {  // no room: give the route up, store nothing of this tile
                 atomicOr(overflow, 1u);
                 s_misc[1] = 1;
@@ -2758,7 +2765,8 @@ struct Tuning {
     bool halves = true;                 // 4-byte keys: pass L-1 hands K4 the low halves only (16-bit array in the workspace)
     bool presample = true;              // a 65 536-key sample before K1h: gross skew goes straight to the LSD route
     bool wide2 = true;                  // 8-byte keys: K4 as two 512-thread blocks per CU (false: one 1024-thread block)
-    bool atomic_route = false;          // 4-byte keys: try ROUTE_ATOMIC (no counting read) before anything else
+    bool atomic_route = true;           // 4-byte keys: try ROUTE_ATOMIC (no counting read) before anything else
+    bool persist_fallback = true;       // behind the atomic route the LSD passes run as persistent blocks (cheap to skip)
     uint64_t hybrid_min_len = 1ull << 28;  // below this the buckets are too small for one workgroup each to pay off
 };
 uint32_t g_ablate = 0;  // only ever set by the RDST_EXPERIMENTS build
@@ -2857,9 +2865,7 @@ Layout make_layout(uint64_t n, uint32_t elem_bytes, uint32_t levels, int cfg, ui
         const uint64_t tiles = (n + TILE - 1) / TILE;
         L.msd_slices = tiles >= 64 * MSD_SLICES ? MSD_SLICES : 1;
         const double mean = (double)n / (RADIX * L.msd_slices);
-        // (a slice = the tiles one XCD happens to run: the dispatcher deals workgroups evenly, an XCD that runs ahead takes a few
-        // more: 6 % of head room instead of the 1 % the key statistics alone would need)
-        const double slack = mean * 0.06 > 8.0 * __builtin_sqrt(mean) ? mean * 0.06 : 8.0 * __builtin_sqrt(mean);
+        const double slack = mean * 0.01 > 8.0 * __builtin_sqrt(mean) ? mean * 0.01 : 8.0 * __builtin_sqrt(mean);
         L.msd_cap_a = (uint32_t)(((uint64_t)(mean + slack) + 2 * TILE / RADIX + 64) / 64 * 64);
         o += align_up(sizeof(uint32_t) * (size_t)L.msd_cap_a * RADIX * L.msd_slices, 256);
     }
@@ -3104,12 +3110,12 @@ int launch_local_sort(K* keys, K* tmp, const uint32_t* bstart, const Plan* plan,
     return RDST_OK;
 }
 
-template <typename K, typename S, int KPT, int NWAVES, int STAGES, bool MAPPED, bool NARROW, typename V = NoVal, bool OUT16 = false>
+template <typename K, typename S, int KPT, int NWAVES, int STAGES, bool MAPPED, bool NARROW, typename V = NoVal, bool OUT16 = false, bool PERSIST = false>
 int launch_pass_t(K* keys, K* tmp, uint64_t n, int level, const Layout& L, char* ws, KeyMap km, int cus, hipStream_t s,
                   V* vals = nullptr, V* vtmp = nullptr, uint16_t* out16 = nullptr) {
     constexpr int TILE = NWAVES * 64 * KPT;
     size_t lds = (size_t)pass_lds_bytes(NWAVES, NARROW ? 4 : 8, ((int)sizeof(K) + ValBytes<V>::value) * (TILE / STAGES));
-    auto kernel = &onesweep_kernel<K, S, KPT, NWAVES, STAGES, MAPPED, NARROW, V, OUT16>;
+    auto kernel = &onesweep_kernel<K, S, KPT, NWAVES, STAGES, MAPPED, NARROW, V, OUT16, PERSIST>;
 #ifdef RDST_EXPERIMENTS
     if (g_exp_lds_total > lds) lds = g_exp_lds_total;  // fewer blocks per CU
 #endif
@@ -3123,9 +3129,10 @@ int launch_pass_t(K* keys, K* tmp, uint64_t n, int level, const Layout& L, char*
     DeviceState* D = nullptr;
     if (int rc = current_device_state(&D)) return rc;
     uint32_t* err = D->err_dev;
-    (void)cus;
-    const dim3 grid((uint32_t)L.tiles), block(NWAVES * 64);  // >= one block per tile of any chain split
-    hipLaunchKernelGGL((onesweep_kernel<K, S, KPT, NWAVES, STAGES, MAPPED, NARROW, V, OUT16>), grid, block, lds, s, keys, tmp, vals, vtmp, out16, n,
+    // >= one block per tile of any chain split; PERSIST: as many blocks as stay resident (two per CU for the shape it is built for)
+    const uint64_t resident = (uint64_t)cus * 2;
+    const dim3 grid((uint32_t)(PERSIST && resident < L.tiles ? resident : L.tiles)), block(NWAVES * 64);
+    hipLaunchKernelGGL((onesweep_kernel<K, S, KPT, NWAVES, STAGES, MAPPED, NARROW, V, OUT16, PERSIST>), grid, block, lds, s, keys, tmp, vals, vtmp, out16, n,
                        level, cbase, status, status_near, chains, ticket, plan, err, (K)km.neg, (K)km.pos, g_ablate | (g_tuning.fast_rank ? RDST_FAST_RANK : 0u) | (g_tuning.fast_rank == 2 ? RDST_FAST_RANK_SELFTEST : 0u));
     HIP_TRY(hipGetLastError());
     return RDST_OK;
@@ -3152,9 +3159,16 @@ bool halves_possible(int cfg, uint64_t n) { return sizeof(K) == 4 && cfg == 4 &&
 
 template <typename K>
 int launch_pass(int cfg, K* keys, K* tmp, uint64_t n, int level, const Layout& L, char* ws, KeyMap km, int cus, hipStream_t s,
-                uint16_t* out16 = nullptr) {
+                uint16_t* out16 = nullptr, bool persist = false) {
     const bool mapped = km.neg != 0 || km.pos != 0;
     const bool narrow = n * sizeof(K) < (1ull << 32);
+    if constexpr (sizeof(K) == 4) {
+        if (persist && cfg == 4 && L.status_bytes == 4 && narrow) {  // the LSD fallback behind the atomic route
+            constexpr int KPT = kpt_for(11, sizeof(K));
+            return mapped ? launch_pass_t<K, uint32_t, KPT, 12, 1, true, true, NoVal, false, true>(keys, tmp, n, level, L, ws, km, cus, s)
+                          : launch_pass_t<K, uint32_t, KPT, 12, 1, false, true, NoVal, false, true>(keys, tmp, n, level, L, ws, km, cus, s);
+        }
+    }
     if constexpr (sizeof(K) == 4) {
         if (out16 && halves_possible<K>(cfg, n) && L.status_bytes == 4 && narrow) {
             constexpr int KPT = kpt_for(11, sizeof(K));
@@ -3403,7 +3417,8 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     for (uint32_t level = level_lo; level < level_hi; ++level) {
         if constexpr (HAS_V) rc = launch_pass_pairs<K, V>(keys, tmp, vals, vtmp, n, (int)level, L, ws, km, D->cus, s);
         else rc = launch_pass<K>(cfg, keys, tmp, n, (int)level, L, ws, km, D->cus, s,
-                                 halves && level + 1 == (uint32_t)LEVELS ? reinterpret_cast<uint16_t*>(ws + L.off_halves) : nullptr);
+                                 halves && level + 1 == (uint32_t)LEVELS ? reinterpret_cast<uint16_t*>(ws + L.off_halves) : nullptr,
+                                 try_atomic && g_tuning.persist_fallback);
         if (rc) return rc;
         if ((rc = prof_mark(*D, s, RDST_STAGE_PASS | (level << 8)))) return rc;
     }
@@ -3671,7 +3686,7 @@ int rdst_hip_set_hybrid(int enabled, uint64_t min_len) {
     g_tuning.halves = enabled != 3;      // 3: counting K4 reading whole keys (no 16-bit hand-off) (A/B, tests)
     g_tuning.presample = enabled != 5;   // 5: no sample before K1h: every hybrid-eligible sort counts all its keys' prefixes first (tests)
     g_tuning.wide2 = enabled != 6;       // 6: 8-byte keys with the one-block-per-CU form of K4 (A/B, tests)
-    g_tuning.atomic_route = enabled == 7;  // 7: ROUTE_ATOMIC for 4-byte keys
+    g_tuning.atomic_route = enabled == 1;  // 1: the default (4-byte keys try the atomic route first); 2..7: the K1h hybrid route for every key width (7: with the default forms of K4)
     g_tuning.hybrid_min_len = min_len ? min_len : (1ull << 28);
     return RDST_OK;
 }

@@ -462,8 +462,8 @@ def profile_run(run: int, levels: int):
 
 
 def set_hybrid(enabled=True, min_len=0):
-    """Route choice knob (rdst_hip_set_hybrid): consider the hybrid route for sorts of at least `min_len` keys
-    (0 = built-in threshold).  enabled == 2: the hybrid route with the generic ranked local sort for 4-byte keys too; 3: counting local sort fed with whole keys (no 16-bit hand-off)."""
+    """Route choice knob (rdst_hip_set_hybrid): consider the byte-saving routes (atomic for 4-byte keys, hybrid for 8-byte keys) for
+    sorts of at least `min_len` keys (0 = built-in threshold); enabled == 7: the hybrid (K1h) route for 4-byte keys too.  enabled == 2: the hybrid route with the generic ranked local sort for 4-byte keys too; 3: counting local sort fed with whole keys (no 16-bit hand-off)."""
     _lib.check(_lib.load().rdst_hip_set_hybrid(int(enabled) if enabled in (2, 3, 5, 6, 7) else int(bool(enabled)), int(min_len)))
 
 

@@ -33,19 +33,19 @@ def _is_sorted(torch, m, chunk=1 << 27):
     return True
 
 
-@pytest.mark.parametrize("name,itype_name,seed,route", [("uint32", "int32", 0x5D570002, "hybrid"), ("uint32", "int32", 0x5D570002, "lsd"),
-                                                         ("uint64", "int64", 0x5D570003, "hybrid"), ("float32", "int32", 0x5D570004, "hybrid"),
-                                                         ("float64", "int64", 0x5D570007, "hybrid")])
+@pytest.mark.parametrize("name,itype_name,seed,route", [("uint32", "int32", 0x5D570002, "atomic"), ("uint32", "int32", 0x5D570002, "hybrid"),
+                                                         ("uint32", "int32", 0x5D570002, "lsd"), ("uint64", "int64", 0x5D570003, "hybrid"),
+                                                         ("float32", "int32", 0x5D570004, "atomic"), ("float64", "int64", 0x5D570007, "hybrid")])
 def test_one_billion_keys(gpu, name, itype_name, seed, route):
-    """`route`: uniform 10^9-key slices take the hybrid route by the device's own choice (asserted); the LSD route
-    — every skewed input's route — is forced once at full size too."""
+    """`route`: uniform 10^9-key slices take the atomic (4-byte keys) / hybrid (8-byte keys) route by the device's own choice
+    (asserted); the hybrid route for 4-byte keys and the LSD route — every skewed input's route — are forced once at full size too."""
     import torch
     itype = getattr(torch, itype_name)
     src = _gen(torch, N, itype, seed)
     keys = src.clone()
     view = keys.view(getattr(torch, name))
     before = gpu.all_level_counts(view)
-    gpu.set_hybrid(route == "hybrid")
+    gpu.set_hybrid({"lsd": False, "hybrid": 7, "atomic": True}[route])
     try:
         gpu.sort_device_tensor(view)
         assert gpu.last_route() == route
@@ -96,25 +96,31 @@ def test_more_than_2_pow_30_keys_uses_wide_status_words(gpu):
     assert _is_sorted(torch, keys ^ torch.iinfo(torch.int32).min)
 
 
-def test_skewed_full_size_inputs_take_the_lsd_route_and_gross_skew_skips_k1h(gpu):
+def test_skewed_full_size_inputs_take_the_lsd_route_and_gross_skew_skips_the_first_pass(gpu):
     """The reference's bimodal bench input (gen_inputs with shift 16, src/test_utils.rs:51-61 / benches/full_sort.rs:68-78) at
-    5·10^8 keys: half the keys share the 16-bit prefix 0 — the 65 536-key sample before K1h sees it and K1h returns at once;
-    an input with ONE bucket one key over the tile is invisible to the sample and must be caught by K1h's exact counts."""
+    5·10^8 keys: half the keys share the 16-bit prefix 0 — the 8 192-key sample sees it and the byte-saving route's first kernel
+    (pass A of the atomic route; K1h of the hybrid one) returns at once; an input with ONE bucket one key over the tile is
+    invisible to the sample and must be caught by the route's own exact check (a slot claim that does not fit; K1h's counts)."""
     import torch
     n = 500_000_000
     src = _gen(torch, n, torch.int32, 0x5D570008)
     bimodal = torch.cat([(src[: n // 2] >> 16) & 0xFFFF, src[n // 2:] << 16])
     borderline = src.clone()
     borderline[:16_897] = (borderline[:16_897] & 0xFFFF) | (0x1234 << 16)   # >= 16 897 keys with prefix 0x1234 (+ ~7 600 random ones)
-    for name, inp, k1h_runs in (("bimodal", bimodal, False), ("borderline", borderline, True)):
-        keys = inp.clone()
-        gpu.sort_device_tensor(keys.view(torch.uint32))   # first use of a kernel loads its code object: not timed
-        keys.copy_(inp)
-        gpu.set_profiling(True)
-        gpu.sort_device_tensor(keys.view(torch.uint32))
-        prof = gpu.profile_run(-1, 4)
-        gpu.set_profiling(False)
-        assert gpu.last_route() == "lsd", name
-        assert (prof["histogram16"] > 0.2) == k1h_runs, (name, prof["histogram16"])   # 0.4 ms when it reads the slice, microseconds when it returns
-        assert int(keys.sum()) == int(inp.sum())
-        assert _is_sorted(torch, keys ^ torch.iinfo(torch.int32).min), name
+    for mode, first in ((True, "msd_pass_a"), (7, "histogram16")):
+        gpu.set_hybrid(mode)
+        try:
+            for name, inp, first_runs in (("bimodal", bimodal, False), ("borderline", borderline, True)):
+                keys = inp.clone()
+                gpu.sort_device_tensor(keys.view(torch.uint32))   # first use of a kernel loads its code object: not timed
+                keys.copy_(inp)
+                gpu.set_profiling(True)
+                gpu.sort_device_tensor(keys.view(torch.uint32))
+                prof = gpu.profile_run(-1, 4)
+                gpu.set_profiling(False)
+                assert gpu.last_route() == "lsd", (mode, name)
+                assert (prof[first] > 0.2) == first_runs, (mode, name, prof[first])   # >= 0.4 ms when it reads the slice, microseconds when it returns
+                assert int(keys.sum()) == int(inp.sum())
+                assert _is_sorted(torch, keys ^ torch.iinfo(torch.int32).min), (mode, name)
+        finally:
+            gpu.set_hybrid(True)

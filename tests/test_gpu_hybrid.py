@@ -17,9 +17,9 @@ TILE = {4: 16896, 8: 16384}  # K4 tile = largest bucket the hybrid route accepts
 @pytest.fixture(params=["count", "count_whole_keys", "ranked", "wide_one_block", "atomic"])
 def hybrid(gpu, request):
     """the forms of K4 for 4-byte keys: the counting sort by value fed with the 16-bit halves pass L-1 leaves in the
-    workspace (default; 8-byte keys: two 512-thread blocks per CU, or — "wide_one_block" — one of 1024), the same fed with whole keys, and the generic ranked passes (what 8-byte keys always use,
-    and the fallback for buckets whose counters overflow)"""
-    mode = {"count": True, "count_whole_keys": 3, "ranked": 2, "wide_one_block": 6, "atomic": 7}[request.param]
+    workspace ("count": the K1h hybrid route; 8-byte keys: two 512-thread blocks per CU, or — "wide_one_block" — one of 1024), the same fed with whole keys, the generic ranked passes (the fallback for buckets whose counters overflow), and "atomic": the library's default, in which
+    4-byte keys take the atomic route (MSD passes that claim space, no counting read) and 8-byte keys the hybrid one"""
+    mode = {"count": 7, "count_whole_keys": 3, "ranked": 2, "wide_one_block": 6, "atomic": True}[request.param]
     gpu.set_hybrid(mode, min_len=1)   # consider the route at every length (default: 2^28 and up)
     gpu._test_mode = request.param
     yield gpu
@@ -163,7 +163,7 @@ def test_float_specials_through_the_hybrid_route(hybrid):
         sp = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, -np.nan, 1.0, -1.0, np.finfo(dtype).tiny, -np.finfo(dtype).tiny], dtype=dtype)
         a[rng.integers(0, a.size, size=5000)] = sp[rng.integers(0, sp.size, size=5000)]
         got, route = _sort(hybrid, a)
-        assert _fast_route(hybrid, route, dtype)
+        assert _fast_route(hybrid, route, dtype, strict=False)   # (a few thousand specials on a handful of top bytes can overflow an area)
         assert same_bits(got, reference_sorted(a))
         k = mapped_key(got)
         assert (k[1:] >= k[:-1]).all()
