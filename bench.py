@@ -121,20 +121,20 @@ def is_sorted(torch, m, chunk=1 << 27):
 
 
 def kernel_table(rdst_amd, runs, n, kb, levels):
-    """per-stage averages over the recorded pipelines: {stage: {avg_ms, launches, GBps, frac}}"""
+    """per-stage averages over the recorded pipelines: {stage: {avg_ms, launches, GBps, frac}}.  Launches that return at once
+    (a level the plan turned off; K1 on the hybrid / atomic routes; the LSD fallback behind a route that succeeded) are
+    listed apart as *_skipped."""
     acc = {}
     for r in runs:
         prof = rdst_amd.profile_run(r, levels)
         if not prof:
             continue
-        top = max(prof["passes"]) if prof["passes"] else 0.0
+        moving = max([ms for nm, _lv, ms in prof["stages"] if nm in ("pass", "msd_pass_a", "msd_pass_b", "local_sort")] or [0.0])
         for name, _level, ms in prof["stages"]:
-            if name == "pass" and ms < 0.25 * top:
-                name = "pass_skipped"          # a level the plan turned off: the launch returns at once
-            if name == "histogram" and prof.get("local_sort", 0.0) > 0.25 * top and ms < 0.1:
-                name = "histogram_skipped"     # K1 returns at once on the hybrid route
+            if name in ("pass", "histogram") and ms < 0.25 * moving and ms < 0.1:
+                name += "_skipped"
             acc.setdefault(name, []).append(ms)
-    alg = {"pass": 2 * kb * n, "local_sort": 2 * kb * n, "histogram": kb * n, "histogram16": kb * n}
+    alg = {"pass": 2 * kb * n, "msd_pass_a": 2 * kb * n, "msd_pass_b": 2 * kb * n, "local_sort": 2 * kb * n, "histogram": kb * n, "histogram16": kb * n}
     out = {}
     for name, v in acc.items():
         avg = sum(v) / len(v)
@@ -144,6 +144,12 @@ def kernel_table(rdst_amd, runs, n, kb, levels):
             e.update({"algorithmic_bytes_per_launch": alg[name], "GBps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 4)})
         out[name] = e
     return out
+
+
+ROUTE_TEXT = {
+    "atomic": "two MSD scatter passes that claim space with atomics (no counting read) + in-LDS sort of every bucket",
+    "hybrid": "K1h (counts of the top 16 bits) + 2 scatter passes on them + in-LDS sort of every bucket",
+}
 
 
 def timed_sorts(torch, rdst_amd, src, name, K, W, step=None, fence=None):
@@ -252,20 +258,27 @@ def main():
     value = total_keys / elapsed / 1e9
     ms_per_step = elapsed / K * 1e3
     roof = None
-    if "pass" in kernels:
-        kp = kernels["pass"]
+    # the dominant kernel: the scatter pass — K3 (onesweep_kernel) on the LSD and hybrid routes, msd_scatter_kernel on the atomic one
+    dom = [k for k in ("msd_pass_a", "msd_pass_b", "pass") if k in kernels and "GBps" in kernels[k]]
+    if dom:
+        launches = sum(kernels[k]["launches"] for k in dom)
+        avg_ms = sum(kernels[k]["avg_ms"] * kernels[k]["launches"] for k in dom) / launches
+        bytes_per_launch = kernels[dom[0]]["algorithmic_bytes_per_launch"]
+        gbps = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         traffic, traffic_src = None, None
         tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tp) and not distributed and n == KEYS_PER_GPU and name == "u32":
             try:
-                traffic = json.load(open(tp)).get("onesweep_pass_hbm_bytes_per_launch")
+                tj = json.load(open(tp))
+                traffic = tj.get("scatter_pass_hbm_bytes_per_launch", tj.get("onesweep_pass_hbm_bytes_per_launch"))
                 traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; not measured in this run)"
             except Exception:  # noqa: BLE001
                 traffic = None
-        roof = {"bound": "hbm", "kernel": "onesweep_kernel (K3, one scatter pass)", "achieved": kp["GBps"],
-                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": kp["frac"], "traffic": traffic, "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": kp["algorithmic_bytes_per_launch"], "avg_launch_ms": kp["avg_ms"],
-                "launches_timed": kp["launches"]}
+        roof = {"bound": "hbm", "kernel": ("msd_scatter_kernel (one MSD scatter pass; mean of passes A and B)" if "msd_pass_a" in dom
+                                           else "onesweep_kernel (K3, one scatter pass)"),
+                "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                "traffic_source": traffic_src, "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": round(avg_ms, 4),
+                "launches_timed": launches}
 
     line = None
     if rank == 0:
@@ -275,8 +288,7 @@ def main():
             "median_ms_per_step": round(statistics.median(per_step), 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": name, "data": "synthetic",
             "config": {"workload": f"{n} uniform-random {name} keys per GPU, device-resident; route '{route}': "
-                                   + ("K1h + 2 scatter passes on the top 16 bits + in-LDS sort of every bucket" if route == "hybrid"
-                                      else f"LSD, {levels} passes x 8 bits")
+                                   + ROUTE_TEXT.get(route, f"LSD, {levels} passes x 8 bits")
                                    + (", sharded: MSD top byte + RCCL all-to-all + local sort" if distributed else ""),
                        "keys_per_gpu": n, "total_keys": n * world, "seed": seed, "route": route,
                        "parallelism": f"shard{world}" if distributed else "single"},

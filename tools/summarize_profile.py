@@ -16,7 +16,7 @@ tag = sys.argv[1]
 levels = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
-KERNELS = ("onesweep_kernel", "hist16_kernel", "hist_kernel", "local_count_sort_kernel", "local_wide_sort_kernel", "local_sort_kernel",
+KERNELS = ("msd_scatter_kernel", "msd_finish_kernel", "presample_kernel", "onesweep_kernel", "hist16_kernel", "hist_kernel", "local_count_sort_kernel", "local_wide_sort_kernel", "local_sort_kernel",
            "route_kernel", "scan_kernel", "clear_unless_hybrid_kernel", "copyback_kernel")
 
 
@@ -45,6 +45,8 @@ for d in sorted(glob.glob(f"{src}/pmc_*/*/*_counter_collection.csv")):
         label = k
         if k == "onesweep_kernel":
             label = f"onesweep_kernel.level{seen[k] % levels}"
+        if k == "msd_scatter_kernel":
+            label = "msd_scatter_kernel.pass_" + "ab"[seen[k] % 2]
         seen[k] += 1
         for c, x in counters.items():
             agg[label][c].append(x)
@@ -63,10 +65,10 @@ for k, v in sorted(out.items()):
         f, w = v["FETCH_SIZE"]["mean_per_launch"] * 1024 * 2, v["WRITE_SIZE"]["mean_per_launch"] * 1024
         if f + w > 1e8:  # launches that moved keys
             traffic["kernels"][k] = {"fetch_bytes_per_launch": f, "write_bytes_per_launch": w, "hbm_bytes_per_launch": f + w}
-moving = [v["hbm_bytes_per_launch"] for k, v in traffic["kernels"].items() if k.startswith("onesweep_kernel.")]
+moving = [v["hbm_bytes_per_launch"] for k, v in traffic["kernels"].items() if k.startswith("onesweep_kernel.") or k.startswith("msd_scatter_kernel.")]
 if moving:
-    traffic["onesweep_pass_hbm_bytes_per_launch"] = sum(moving) / len(moving)   # mean over the levels that moved keys (bench.py: roofline.traffic)
-    traffic["onesweep_levels_that_moved_keys"] = len(moving)
+    traffic["scatter_pass_hbm_bytes_per_launch"] = sum(moving) / len(moving)   # mean over the scatter launches that moved keys (bench.py: roofline.traffic)
+    traffic["scatter_launches_that_moved_keys"] = len(moving)
     traffic["algorithmic_bytes_per_launch"] = 8_000_000_000
     json.dump(traffic, open("profiles/pmc_traffic.json", "w"), indent=1)
     json.dump(traffic, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
@@ -82,7 +84,7 @@ if traces:
         k = short(r["Kernel_Name"])
         if not k:
             continue
-        label = f"onesweep_kernel.level{seen[k] % levels}" if k == "onesweep_kernel" else k
+        label = f"onesweep_kernel.level{seen[k] % levels}" if k == "onesweep_kernel" else ("msd_scatter_kernel.pass_" + "ab"[seen[k] % 2] if k == "msd_scatter_kernel" else k)
         seen[k] += 1
         dur[label].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
     bench_line = None
@@ -96,12 +98,13 @@ if traces:
         summ["per_kernel_ms"][k] = {"launches": len(v), "avg_ms_all": round(sum(v) / len(v), 4),
                                     "avg_ms_timed_steps": round(sum(timed) / max(1, len(timed)), 4),
                                     "launch_ms": [round(x, 4) for x in v]}
-    moved = [v["avg_ms_timed_steps"] for k, v in summ["per_kernel_ms"].items() if k.startswith("onesweep_kernel.") and v["avg_ms_timed_steps"] > 0.3]
+    moved = [v["avg_ms_timed_steps"] for k, v in summ["per_kernel_ms"].items()
+             if (k.startswith("onesweep_kernel.") or k.startswith("msd_scatter_kernel.")) and v["avg_ms_timed_steps"] > 0.3]
     if moved:
-        summ["onesweep_avg_ms_timed_steps_levels_that_moved_keys"] = round(sum(moved) / len(moved), 4)
+        summ["scatter_avg_ms_timed_steps_launches_that_moved_keys"] = round(sum(moved) / len(moved), 4)
     summ["bench_line_of_the_same_run"] = bench_line
     json.dump(summ, open(f"profiles/{tag}_kernel_trace_summary.json", "w"), indent=1)
-    print("onesweep avg over the levels that moved keys (timed steps, trace): %s ms; bench events in the same run: %s ms" % (
-        summ.get("onesweep_avg_ms_timed_steps_levels_that_moved_keys"), bench_line and bench_line["roofline"]["avg_launch_ms"]))
+    print("scatter pass avg over the launches that moved keys (timed steps, trace): %s ms; bench events in the same run: %s ms" % (
+        summ.get("scatter_avg_ms_timed_steps_launches_that_moved_keys"), bench_line and bench_line["roofline"]["avg_launch_ms"]))
     for k, v in summ["per_kernel_ms"].items():
         print("  %-32s %3d launches  avg(timed) %.4f ms" % (k, v["launches"], v["avg_ms_timed_steps"]))
