@@ -199,6 +199,19 @@ __device__ __forceinline__ K lane_below(K x) {
     }
 }
 
+// value held by lane 63 (wave-uniform result)
+template <typename K>
+__device__ __forceinline__ K lane63_of(K x) {
+    if constexpr (sizeof(K) <= 4) {
+        return (K)(uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+    } else {
+        K r = 0;
+#pragma unroll
+        for (int w = 0; w < (int)sizeof(K) / 4; ++w) r |= (K)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> (32 * w)), 63) << (32 * w);
+        return r;
+    }
+}
+
 // lanes of this wave holding the same 8-bit digit (all 64 lanes must be active)
 __device__ __forceinline__ uint64_t match_any8(uint32_t d) {
     uint64_t m = ~0ull;
@@ -1511,18 +1524,19 @@ ranked:
 // (top digit of the source area, digit) of dst_cap keys, low halves only (HALVES).  A claim that would pass the capacity
 // raises *overflow and stores nothing.  The key map is applied for the digit and, for whole keys, undone at the store.
 // ------------------------------------------------------------------------------------------
-template <int KPT, int NWAVES, bool MAPPED, bool HALVES>
+// SECOND: pass B (sources are pass A's areas, destinations the bucket slots); HALVES: 4-byte keys' pass B stores low halves.
+template <typename K, int KPT, int NWAVES, bool MAPPED, bool SECOND, bool HALVES>
 __global__ __launch_bounds__(NWAVES * 64, (2 * NWAVES + 3) / 4) void msd_scatter_kernel(
-    const uint32_t* __restrict__ src, const uint32_t* __restrict__ area_count /* nullable: one area of n keys */, uint64_t n, uint32_t area_cap,
-    uint32_t tiles_per_area, uint32_t* __restrict__ dst, uint16_t* __restrict__ dst16, uint32_t* __restrict__ cursor, uint32_t dst_cap, int shift,
+    const K* __restrict__ src, const uint32_t* __restrict__ area_count /* nullable: one area of n keys */, uint64_t n, uint32_t area_cap,
+    uint32_t tiles_per_area, K* __restrict__ dst, uint16_t* __restrict__ dst16, uint32_t* __restrict__ cursor, uint32_t dst_cap, int shift,
     uint32_t slices /* areas per top digit (pass A: of the destination, pass B: of the source) */,
     const Plan* __restrict__ plan, uint32_t* __restrict__ overflow, uint32_t* __restrict__ inversion /* pass A sets it; pass B reads it */,
-    uint32_t neg, uint32_t pos) {
-    using K = uint32_t;
+    K neg, K pos) {
+    static_assert(!HALVES || (SECOND && sizeof(K) == 4), "halves: the second pass of 4-byte keys");
     constexpr int BLOCK = NWAVES * 64, TILE = BLOCK * KPT;
-    constexpr uint32_t SLOT_UNIT = 4;
+    constexpr uint32_t SLOT_UNIT = (uint32_t)sizeof(K);
     if (plan->gross_skew || *overflow) return;  // the sample or an earlier pass already gave the route up
-    if (HALVES && *inversion == 0) return;      // pass A met no inversion: the slice is sorted, nothing to do
+    if (SECOND && *inversion == 0) return;      // pass A met no inversion: the slice is sorted, nothing to do
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* wave_hist = reinterpret_cast<uint32_t*>(smem);                           // [NWAVES][256]
     uint32_t* s_delta = reinterpret_cast<uint32_t*>(smem + NWAVES * 1024);             // [256] destination of tile slot 0 of a digit's run (elements, mod 2^32)
@@ -1542,7 +1556,7 @@ __global__ __launch_bounds__(NWAVES * 64, (2 * NWAVES + 3) / 4) void msd_scatter
     // pass A reads the caller's slice in its order: the already-sorted exit (src/sorter.rs:59-65) looks here.  Index order is
     // (wave, round, lane): the key before a wave's first is fetched with the tile (one lane), the others are in registers
     K edge = 0;
-    if constexpr (!HALVES) {
+    if constexpr (!SECOND) {
         if (lane == 0 && tile_off + (uint64_t)wave * 64u * KPT > 0 && (uint32_t)wave * 64u * KPT < valid) edge = tsrc[(int64_t)wbase - 1];
     }
     if (full) {
@@ -1564,14 +1578,14 @@ __global__ __launch_bounds__(NWAVES * 64, (2 * NWAVES + 3) / 4) void msd_scatter
             mk[i] = v;
         }
     }
-    if constexpr (!HALVES) {
+    if constexpr (!SECOND) {
         if constexpr (MAPPED) edge = map_key<K>(edge, neg, pos);
         if (tile_off + (uint64_t)wave * 64u * KPT == 0) edge = 0;  // the slice's first key has no predecessor
         bool inv = false;
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
             K before = lane_below<K>(mk[i]);
-            if (lane == 0) before = i == 0 ? edge : (K)__builtin_amdgcn_readlane((int)mk[i > 0 ? i - 1 : 0], 63);
+            if (lane == 0) before = i == 0 ? edge : lane63_of<K>(mk[i > 0 ? i - 1 : 0]);
             inv |= before > mk[i];  // (padding is the largest key and sits at the end: it never counts as an inversion)
         }
         // (one word for the whole grid: look before setting — 700 000 waves OR-ing the same word took 8 ms, ~88 atomics per us)
@@ -1600,7 +1614,7 @@ __global__ __launch_bounds__(NWAVES * 64, (2 * NWAVES + 3) / 4) void msd_scatter
                     uniform_rounds |= 1u << i;
                 } else {
                     uint32_t total;
-                    const uint32_t below = peers_below_total(mk[i], bit0, total);
+                    const uint32_t below = peers_below_total(digit_word<K>(mk[i], shift), bit0, total);
                     if (below == 0) atomicAdd(&wh[d], total);
                 }
             }
@@ -1652,7 +1666,7 @@ __global__ __launch_bounds__(NWAVES * 64, (2 * NWAVES + 3) / 4) void msd_scatter
         // pass A: area (slice, digit) — blocks b and b + 8 share an XCD, so a digit's 8 frontiers stay with one L2 each, and the
         // tiles are dealt to the slices in turn: every slice gets its share of the keys give or take a tile;
         // pass B: slot (top digit of the source area, digit)
-        const uint32_t where = HALVES ? (area % RADIX) * RADIX + (uint32_t)tid : (blockIdx.x % slices) * RADIX + (uint32_t)tid;
+        const uint32_t where = SECOND ? (area % RADIX) * RADIX + (uint32_t)tid : (blockIdx.x % slices) * RADIX + (uint32_t)tid;
         uint32_t got = 0;
         if (pub) {
             // (Pass A has only 256 x 8 counters for ~59 000 tiles x 256 claims.  Measured: device-scope claims cost the pass nothing —
@@ -1679,7 +1693,7 @@ __global__ __launch_bounds__(NWAVES * 64, (2 * NWAVES + 3) / 4) void msd_scatter
         for (int i = 0; i < KPT; ++i) {
             uint32_t* slot = &wh[digit_of(mk[i], shift)];
             const uint32_t b = *slot;
-            const uint32_t below = peers_below(mk[i], bit0);
+            const uint32_t below = peers_below(digit_word<K>(mk[i], shift), bit0);
             __builtin_amdgcn_wave_barrier();
             atomicAdd(slot, SLOT_UNIT);
             *reinterpret_cast<K*>(reinterpret_cast<unsigned char*>(s_keys) + b + below * SLOT_UNIT) = mk[i];
@@ -1696,7 +1710,7 @@ __global__ __launch_bounds__(NWAVES * 64, (2 * NWAVES + 3) / 4) void msd_scatter
                 if (lane == 0) *slot = b + 64u * SLOT_UNIT;
             } else {
                 uint32_t total;
-                below = peers_below_total(mk[i], bit0, total);
+                below = peers_below_total(digit_word<K>(mk[i], shift), bit0, total);
                 __builtin_amdgcn_wave_barrier();
                 if (below == 0) *slot = b + total * SLOT_UNIT;
             }
@@ -1842,7 +1856,8 @@ constexpr size_t local_lds_bytes(size_t key_bytes) { return (size_t)local_waves(
 
 template <typename K, int NWAVES, int KPT, bool MAPPED>
 __device__ __forceinline__ void local_sort_bucket(K* __restrict__ buf, const uint16_t* __restrict__ src16 /* nullable: low halves of the mapped keys */,
-                                                  const uint32_t soff /* where they lie in src16 */, const uint32_t bucket, const uint32_t start, const uint32_t cnt,
+                                                  const K* __restrict__ alt_src /* nullable: whole (raw) keys lie here, not at their final place */,
+                                                  const uint32_t soff /* where the bucket lies in src16 / alt_src */, const uint32_t bucket, const uint32_t start, const uint32_t cnt,
                                                   uint32_t* __restrict__ err, K neg, K pos, uint32_t flags) {
     constexpr int BLOCK = NWAVES * 64, TILE = BLOCK * KPT, W = sizeof(K) * 8, LOCAL = (int)sizeof(K) - 2;
     constexpr uint32_t SLOT_UNIT = (uint32_t)sizeof(K);  // running slots count in bytes of the staging buffer
@@ -1853,6 +1868,7 @@ __device__ __forceinline__ void local_sort_bucket(K* __restrict__ buf, const uin
             const K m = (K)((K)bucket << (W - 16)) | (K)src16[soff];
             buf[start] = MAPPED ? unmap_key<K>(m, neg, pos) : m;
         }
+        if (alt_src && cnt == 1 && tid == 0) buf[start] = alt_src[soff];
         return;
     }
     if (cnt > (uint32_t)TILE) {  // the route test rules it out; never sort a truncated bucket
@@ -1872,7 +1888,7 @@ __device__ __forceinline__ void local_sort_bucket(K* __restrict__ buf, const uin
     __builtin_amdgcn_s_setprio(RDST_PRIO_LOAD);
     K mk[KPT];
     {
-        const K* tsrc = buf + start;
+        const K* tsrc = alt_src ? alt_src + soff : buf + start;
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
             K v = sentinel;
@@ -2053,13 +2069,13 @@ template <typename K, int NWAVES, int KPT, bool MAPPED>
 __global__ __launch_bounds__(NWAVES * 64, (sizeof(K) <= 4 ? 2 : 1) * NWAVES / 4) void local_sort_kernel(
     K* __restrict__ buf_keys, K* __restrict__ buf_tmp, const uint32_t* __restrict__ bstart, const Plan* __restrict__ plan,
     uint32_t* __restrict__ err, K neg, K pos, uint32_t flags, const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count,
-    const uint16_t* __restrict__ src16, const uint32_t* __restrict__ slot_count, uint32_t slot_cap) {
+    const uint16_t* __restrict__ src16, const uint32_t* __restrict__ slot_count, uint32_t slot_cap, const K* __restrict__ alt_src) {
     if (!plan->local_sort) return;
     K* __restrict__ buf = plan->result_in_tmp ? buf_tmp : buf_keys;
     if (list == nullptr) {
         const uint32_t bucket = blockIdx.x;
         const uint32_t start = bstart[bucket];
-        local_sort_bucket<K, NWAVES, KPT, MAPPED>(buf, src16, start, bucket, start, bstart[bucket + 1] - start, err, neg, pos, flags);
+        local_sort_bucket<K, NWAVES, KPT, MAPPED>(buf, src16, nullptr, start, bucket, start, bstart[bucket + 1] - start, err, neg, pos, flags);
         return;
     }
     const uint32_t todo = *list_count;
@@ -2068,7 +2084,7 @@ __global__ __launch_bounds__(NWAVES * 64, (sizeof(K) <= 4 ? 2 : 1) * NWAVES / 4)
         const uint32_t bucket = list[e];
         const uint32_t start = bstart[bucket];
         const uint32_t cnt = slot_count ? slot_count[bucket] : bstart[bucket + 1] - start;
-        local_sort_bucket<K, NWAVES, KPT, MAPPED>(buf, src16, slot_count ? bucket * slot_cap : start, bucket, start, cnt, err, neg, pos, flags);
+        local_sort_bucket<K, NWAVES, KPT, MAPPED>(buf, src16, alt_src, slot_count ? bucket * slot_cap : start, bucket, start, cnt, err, neg, pos, flags);
         __syncthreads();  // the next bucket reuses the LDS
     }
 }
@@ -2387,7 +2403,9 @@ constexpr size_t wide2_lds_bytes() { return 32768 + 8192 + 2 * (size_t)local_til
 template <bool MAPPED>
 __global__ __launch_bounds__(WIDE2_THREADS, 8) void local_wide2_sort_kernel(
     uint64_t* __restrict__ buf_keys, uint64_t* __restrict__ buf_tmp, const uint32_t* __restrict__ bstart, const Plan* __restrict__ plan,
-    uint32_t* __restrict__ err, uint64_t neg, uint64_t pos, uint32_t* __restrict__ list, uint32_t* __restrict__ list_count) {
+    uint32_t* __restrict__ err, uint64_t neg, uint64_t pos, uint32_t* __restrict__ list, uint32_t* __restrict__ list_count,
+    const uint64_t* __restrict__ src_slots /* ROUTE_ATOMIC: bucket b's keys lie in slot b (slot_cap keys) and number slot_count[b]; NULL: in place */,
+    const uint32_t* __restrict__ slot_count, uint32_t slot_cap) {
     constexpr int TILE = local_tile(8);
     constexpr int BLOCK = WIDE2_THREADS, MAXR = TILE / BLOCK, WPT = H16_BINS / BLOCK / 8, LOG_VPT = 6;
     constexpr int HALF = TILE / 2;
@@ -2395,8 +2413,8 @@ __global__ __launch_bounds__(WIDE2_THREADS, 8) void local_wide2_sort_kernel(
     if (!plan->local_sort) return;
     uint64_t* __restrict__ buf = plan->result_in_tmp ? buf_tmp : buf_keys;
     const uint32_t bucket = blockIdx.x;
-    const uint32_t start = bstart[bucket], cnt = bstart[bucket + 1] - start;
-    if (cnt <= 1) return;
+    const uint32_t start = bstart[bucket], cnt = src_slots ? slot_count[bucket] : bstart[bucket + 1] - start;
+    if (cnt == 0 || (cnt == 1 && !src_slots)) return;  // (a single key in a slot still has to be moved to its place)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (cnt > (uint32_t)TILE) {
         if (tid == 0) atomicOr(err, ERR_LOCAL_OVERFLOW);
@@ -2409,7 +2427,7 @@ __global__ __launch_bounds__(WIDE2_THREADS, 8) void local_wide2_sort_kernel(
     uint64_t* out64 = reinterpret_cast<uint64_t*>(smem);                             // [HALF] output staging (everything above is dead by then)
     uint32_t* s_wsum = reinterpret_cast<uint32_t*>(smem + 32768 + 8192 + 2 * TILE);  // [8] wave sums, [16] overflow / ambiguity flag
     __builtin_amdgcn_s_setprio(RDST_PRIO_LOAD);
-    const uint64_t* tsrc = buf + start;
+    const uint64_t* tsrc = src_slots ? src_slots + (uint64_t)bucket * slot_cap : buf + start;
     uint64_t mk[MAXR];
 #pragma unroll
     for (int i = 0; i < MAXR; ++i) {
@@ -2766,6 +2784,7 @@ struct Tuning {
     bool presample = true;              // a 65 536-key sample before K1h: gross skew goes straight to the LSD route
     bool wide2 = true;                  // 8-byte keys: K4 as two 512-thread blocks per CU (false: one 1024-thread block)
     bool atomic_route = true;           // 4-byte keys: try ROUTE_ATOMIC (no counting read) before anything else
+    bool atomic_wide = true;            // ROUTE_ATOMIC for 8-byte keys too (whole keys in the slots)
     bool persist_fallback = true;       // behind the atomic route the LSD passes run as persistent blocks (cheap to skip)
     uint64_t hybrid_min_len = 1ull << 28;  // below this the buckets are too small for one workgroup each to pay off
 };
@@ -2806,6 +2825,9 @@ struct DeviceState {
     std::vector<ProfRun> prof_runs;  // one per pipeline since profiling was (re-)enabled
 };
 DeviceState g_dev[16];
+
+constexpr int MSD_WAVES = 12;
+constexpr int msd_kpt(size_t key_bytes) { return key_bytes == 4 ? 22 : 11; }  // ROUTE_ATOMIC tiles: 66 KiB of keys, two blocks per CU
 
 struct Layout {
     uint32_t levels, tile, status_bytes;  // status_bytes: 4 or 8 per word
@@ -2854,20 +2876,21 @@ Layout make_layout(uint64_t n, uint32_t elem_bytes, uint32_t levels, int cfg, ui
     o = align_up(o, 256);
     L.off_halves = o;                                                       // hybrid route, 4-byte keys: low halves between pass L-1 and K4
     if (want_halves && !want_msd) o += align_up(sizeof(uint16_t) * n, 256);
-    if (want_msd) o += align_up(sizeof(uint16_t) * (size_t)H16_BINS * local_tile(4), 256);  // ROUTE_ATOMIC: 65 536 slots of one K4 tile
+    // ROUTE_ATOMIC: 65 536 slots of one K4 tile each — low halves of 4-byte keys, whole 8-byte keys
+    if (want_msd) o += align_up((elem_bytes == 4 ? sizeof(uint16_t) : (size_t)elem_bytes) * H16_BINS * local_tile(elem_bytes), 256);
     L.off_msd_a = o;
     L.msd_cap_a = 0;
     L.msd_slices = 1;
     if (want_msd) {
         // areas of pass A: tiles are dealt to the slices in turn, so a slice gets its share of the keys give or take a tile;
         // capacity = mean + max(1 %, 8 sigma) + two tiles' worth of one digit, whole 64s.  Few tiles: one slice.
-        constexpr uint64_t TILE = 12 * 64 * 22;
+        const uint64_t TILE = (uint64_t)MSD_WAVES * 64 * msd_kpt(elem_bytes);
         const uint64_t tiles = (n + TILE - 1) / TILE;
         L.msd_slices = tiles >= 64 * MSD_SLICES ? MSD_SLICES : 1;
         const double mean = (double)n / (RADIX * L.msd_slices);
         const double slack = mean * 0.01 > 8.0 * __builtin_sqrt(mean) ? mean * 0.01 : 8.0 * __builtin_sqrt(mean);
         L.msd_cap_a = (uint32_t)(((uint64_t)(mean + slack) + 2 * TILE / RADIX + 64) / 64 * 64);
-        o += align_up(sizeof(uint32_t) * (size_t)L.msd_cap_a * RADIX * L.msd_slices, 256);
+        o += align_up((size_t)elem_bytes * L.msd_cap_a * RADIX * L.msd_slices, 256);
     }
     L.total = align_up(o, 256);
     return L;
@@ -2941,11 +2964,12 @@ int prof_mark(DeviceState& D, hipStream_t s, uint32_t kind = 0) {
     return RDST_OK;
 }
 
-// ROUTE_ATOMIC: 4-byte keys, and a length at which a uniform bucket (n / 65 536 keys) stays 8 sigma below the K4 tile
+// ROUTE_ATOMIC: 4- and 8-byte keys, and a length at which a uniform bucket (n / 65 536 keys) stays 8 sigma below the K4 tile
 bool atomic_eligible(uint64_t n, size_t key_bytes, int cfg) {
-    if (!g_tuning.hybrid || !g_tuning.atomic_route || key_bytes != 4 || cfg != 4 || n < g_tuning.hybrid_min_len || n >= (1ull << 30)) return false;
+    if (!g_tuning.hybrid || !g_tuning.atomic_route || n < g_tuning.hybrid_min_len || n >= (1ull << 30)) return false;
+    if (key_bytes == 4 ? cfg != 4 : (key_bytes != 8 || !g_tuning.atomic_wide || !g_tuning.count_sort || !g_tuning.wide2)) return false;
     const double mean = (double)n / H16_BINS;
-    return mean + 8.0 * __builtin_sqrt(mean) <= (double)local_tile(4);
+    return mean + 8.0 * __builtin_sqrt(mean) <= (double)local_tile(key_bytes);
 }
 
 bool hybrid_eligible(uint64_t n, size_t key_bytes) {
@@ -3052,7 +3076,7 @@ constexpr int COUNT_THREADS = RDST_COUNT_THREADS;
 template <typename K>
 int launch_local_sort(K* keys, K* tmp, const uint32_t* bstart, const Plan* plan, uint32_t* err, KeyMap km, uint32_t* list,
                       uint32_t* list_count, const uint16_t* src16, int cus, hipStream_t s, const uint32_t* slot_count = nullptr,
-                      uint32_t slot_cap = 0) {
+                      uint32_t slot_cap = 0, const K* src_slots = nullptr) {
     constexpr int NW = local_waves(sizeof(K)), KPT = local_kpt(sizeof(K));
     constexpr size_t lds = local_lds_bytes(sizeof(K));
     const bool mapped = km.neg != 0 || km.pos != 0;
@@ -3081,10 +3105,10 @@ int launch_local_sort(K* keys, K* tmp, const uint32_t* bstart, const Plan* plan,
                 constexpr size_t w2 = wide2_lds_bytes();
                 if (mapped) {
                     if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_wide2_sort_kernel<true>), w2)) return rc;
-                    hipLaunchKernelGGL((local_wide2_sort_kernel<true>), dim3(H16_BINS), dim3(WIDE2_THREADS), w2, s, keys, tmp, bstart, plan, err, (uint64_t)km.neg, (uint64_t)km.pos, list, list_count);
+                    hipLaunchKernelGGL((local_wide2_sort_kernel<true>), dim3(H16_BINS), dim3(WIDE2_THREADS), w2, s, keys, tmp, bstart, plan, err, (uint64_t)km.neg, (uint64_t)km.pos, list, list_count, src_slots, slot_count, slot_cap);
                 } else {
                     if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_wide2_sort_kernel<false>), w2)) return rc;
-                    hipLaunchKernelGGL((local_wide2_sort_kernel<false>), dim3(H16_BINS), dim3(WIDE2_THREADS), w2, s, keys, tmp, bstart, plan, err, (uint64_t)km.neg, (uint64_t)km.pos, list, list_count);
+                    hipLaunchKernelGGL((local_wide2_sort_kernel<false>), dim3(H16_BINS), dim3(WIDE2_THREADS), w2, s, keys, tmp, bstart, plan, err, (uint64_t)km.neg, (uint64_t)km.pos, list, list_count, src_slots, slot_count, slot_cap);
                 }
             } else if (mapped) {
                 if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_wide_sort_kernel<true>), wlds)) return rc;
@@ -3101,10 +3125,10 @@ int launch_local_sort(K* keys, K* tmp, const uint32_t* bstart, const Plan* plan,
     const uint32_t* wl = listed ? list : nullptr;
     if (mapped) {
         if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_sort_kernel<K, NW, KPT, true>), lds)) return rc;
-        hipLaunchKernelGGL((local_sort_kernel<K, NW, KPT, true>), grid, dim3(NW * 64), lds, s, keys, tmp, bstart, plan, err, (K)km.neg, (K)km.pos, flags, wl, list_count, src16, slot_count, slot_cap);
+        hipLaunchKernelGGL((local_sort_kernel<K, NW, KPT, true>), grid, dim3(NW * 64), lds, s, keys, tmp, bstart, plan, err, (K)km.neg, (K)km.pos, flags, wl, list_count, src16, slot_count, slot_cap, src_slots);
     } else {
         if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_sort_kernel<K, NW, KPT, false>), lds)) return rc;
-        hipLaunchKernelGGL((local_sort_kernel<K, NW, KPT, false>), grid, dim3(NW * 64), lds, s, keys, tmp, bstart, plan, err, (K)km.neg, (K)km.pos, flags, wl, list_count, src16, slot_count, slot_cap);
+        hipLaunchKernelGGL((local_sort_kernel<K, NW, KPT, false>), grid, dim3(NW * 64), lds, s, keys, tmp, bstart, plan, err, (K)km.neg, (K)km.pos, flags, wl, list_count, src16, slot_count, slot_cap, src_slots);
     }
     HIP_TRY(hipGetLastError());
     return RDST_OK;
@@ -3167,6 +3191,12 @@ int launch_pass(int cfg, K* keys, K* tmp, uint64_t n, int level, const Layout& L
             constexpr int KPT = kpt_for(11, sizeof(K));
             return mapped ? launch_pass_t<K, uint32_t, KPT, 12, 1, true, true, NoVal, false, true>(keys, tmp, n, level, L, ws, km, cus, s)
                           : launch_pass_t<K, uint32_t, KPT, 12, 1, false, true, NoVal, false, true>(keys, tmp, n, level, L, ws, km, cus, s);
+        }
+    }
+    if constexpr (sizeof(K) == 8) {
+        if (persist && cfg == 5 && L.status_bytes == 4) {  // the same for 8-byte keys (64-bit deltas at every length: one shape)
+            return mapped ? launch_pass_t<K, uint32_t, 10, 12, 1, true, false, NoVal, false, true>(keys, tmp, n, level, L, ws, km, cus, s)
+                          : launch_pass_t<K, uint32_t, 10, 12, 1, false, false, NoVal, false, true>(keys, tmp, n, level, L, ws, km, cus, s);
         }
     }
     if constexpr (sizeof(K) == 4) {
@@ -3245,6 +3275,8 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     // K1 runs as ever (the slice is then read twice for counting); if it says hybrid, K1 returns at once.
     const bool whole_sort = !HAS_V && level_lo == 0 && level_hi == (uint32_t)LEVELS && allow_skip && copy_back;
     const bool try_atomic = whole_sort && atomic_eligible(n, sizeof(K), cfg);  // (its fallback is the LSD route: K1h is not tried then)
+    // 8-byte keys: the fallback's passes run as persistent blocks of shape 5 (eight skipped passes of one block per tile cost 0.5 ms per 10^9 keys)
+    if (try_atomic && sizeof(K) == 8 && g_tuning.persist_fallback && g_tuning.pass_cfg < 0) cfg = 5;
     const bool try_hybrid = whole_sort && !try_atomic && hybrid_eligible(n, sizeof(K));
     const bool halves = try_hybrid && g_tuning.halves && g_tuning.count_sort && halves_possible<K>(cfg, n);
     const Layout L = make_layout(n, sizeof(K), LEVELS, cfg, HAS_V ? PAIR_WAVES * 64 * pair_kpt(sizeof(K), ValBytes<V>::value) : 0, halves, try_atomic);
@@ -3301,33 +3333,36 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     const bool pair = g_tuning.chains && LEVELS >= 2 && level_hi > level_lo + 1;
     unsigned long long* hpair = reinterpret_cast<unsigned long long*>(ws + L.off_hpair);
     Plan* plan = reinterpret_cast<Plan*>(ws + L.off_plan);
-    if constexpr (!HAS_V && sizeof(K) == 4) {
+    if constexpr (!HAS_V && (sizeof(K) == 4 || sizeof(K) == 8)) {
         if (try_atomic) {
-            constexpr int KPT = 22, NW = 12, TILE = NW * 64 * KPT;
-            constexpr size_t mlds = (size_t)NW * 1024 + 1024 + 64 + sizeof(uint32_t) * TILE;
+            constexpr int KPT = msd_kpt(sizeof(K)), NW = MSD_WAVES, TILE = NW * 64 * KPT, W = (int)sizeof(K) * 8;
+            constexpr bool HALF = sizeof(K) == 4;  // 4-byte keys leave pass B as their low halves
+            constexpr size_t mlds = (size_t)NW * 1024 + 1024 + 64 + sizeof(K) * TILE;
+            const uint32_t slot_cap = (uint32_t)local_tile(sizeof(K));
             uint32_t* overflow = reinterpret_cast<uint32_t*>(ws + L.off_err) + 4;
             uint32_t* cursor_a = reinterpret_cast<uint32_t*>(ws + L.off_cursor_a);
             uint32_t* cursor_b = reinterpret_cast<uint32_t*>(ws + L.off_cursor_b);
-            uint32_t* area_a = reinterpret_cast<uint32_t*>(ws + L.off_msd_a);
-            uint16_t* slots = reinterpret_cast<uint16_t*>(ws + L.off_halves);
+            K* area_a = reinterpret_cast<K*>(ws + L.off_msd_a);
+            uint16_t* slots16 = HALF ? reinterpret_cast<uint16_t*>(ws + L.off_halves) : nullptr;
+            K* slots = HALF ? nullptr : reinterpret_cast<K*>(ws + L.off_halves);
             const bool mapped = km.neg != 0 || km.pos != 0;
             if ((rc = launch_presample<K>(keys, n, km, plan, s))) return rc;
             const uint32_t tiles_a = (uint32_t)((n + TILE - 1) / TILE);
             const uint32_t tpa = (L.msd_cap_a + TILE - 1) / TILE;
-#define RDST_MSD(MAPPED, HALVES, GRID, ...)                                                                                          \
-    do {                                                                                                                             \
-        if ((rc = ensure_lds_attr(reinterpret_cast<const void*>(&msd_scatter_kernel<KPT, NW, MAPPED, HALVES>), mlds))) return rc;    \
-        hipLaunchKernelGGL((msd_scatter_kernel<KPT, NW, MAPPED, HALVES>), dim3(GRID), dim3(NW * 64), mlds, s, __VA_ARGS__);          \
+#define RDST_MSD(MAPPED, SECOND, GRID, ...)                                                                                              \
+    do {                                                                                                                                 \
+        if ((rc = ensure_lds_attr(reinterpret_cast<const void*>(&msd_scatter_kernel<K, KPT, NW, MAPPED, SECOND, (SECOND && HALF)>), mlds))) return rc; \
+        hipLaunchKernelGGL((msd_scatter_kernel<K, KPT, NW, MAPPED, SECOND, (SECOND && HALF)>), dim3(GRID), dim3(NW * 64), mlds, s, __VA_ARGS__); \
     } while (0)
             // pass A: the slice, by its top byte, into 256 x 8 areas
-            if (mapped) RDST_MSD(true, false, tiles_a, reinterpret_cast<const uint32_t*>(keys), nullptr, n, 0u, tiles_a, area_a, nullptr, cursor_a, L.msd_cap_a, 24, L.msd_slices, plan, overflow, inversion, (uint32_t)km.neg, (uint32_t)km.pos);
-            else RDST_MSD(false, false, tiles_a, reinterpret_cast<const uint32_t*>(keys), nullptr, n, 0u, tiles_a, area_a, nullptr, cursor_a, L.msd_cap_a, 24, L.msd_slices, plan, overflow, inversion, (uint32_t)km.neg, (uint32_t)km.pos);
+            if (mapped) RDST_MSD(true, false, tiles_a, keys, nullptr, n, 0u, tiles_a, area_a, nullptr, cursor_a, L.msd_cap_a, W - 8, L.msd_slices, plan, overflow, inversion, (K)km.neg, (K)km.pos);
+            else RDST_MSD(false, false, tiles_a, keys, nullptr, n, 0u, tiles_a, area_a, nullptr, cursor_a, L.msd_cap_a, W - 8, L.msd_slices, plan, overflow, inversion, (K)km.neg, (K)km.pos);
             HIP_TRY(hipGetLastError());
             if ((rc = prof_mark(*D, s, RDST_STAGE_MSD_A))) return rc;
-            // pass B: every area, by the second byte, into the slot of its bucket (low halves)
+            // pass B: every area, by the second byte, into the slot of its bucket
             const uint32_t grid_b = (uint32_t)RADIX * L.msd_slices * tpa;
-            if (mapped) RDST_MSD(true, true, grid_b, area_a, cursor_a, 0ull, L.msd_cap_a, tpa, nullptr, slots, cursor_b, (uint32_t)local_tile(4), 16, L.msd_slices, plan, overflow, inversion, (uint32_t)km.neg, (uint32_t)km.pos);
-            else RDST_MSD(false, true, grid_b, area_a, cursor_a, 0ull, L.msd_cap_a, tpa, nullptr, slots, cursor_b, (uint32_t)local_tile(4), 16, L.msd_slices, plan, overflow, inversion, (uint32_t)km.neg, (uint32_t)km.pos);
+            if (mapped) RDST_MSD(true, true, grid_b, area_a, cursor_a, 0ull, L.msd_cap_a, tpa, slots, slots16, cursor_b, slot_cap, W - 16, L.msd_slices, plan, overflow, inversion, (K)km.neg, (K)km.pos);
+            else RDST_MSD(false, true, grid_b, area_a, cursor_a, 0ull, L.msd_cap_a, tpa, slots, slots16, cursor_b, slot_cap, W - 16, L.msd_slices, plan, overflow, inversion, (K)km.neg, (K)km.pos);
 #undef RDST_MSD
             HIP_TRY(hipGetLastError());
             if ((rc = prof_mark(*D, s, RDST_STAGE_MSD_B))) return rc;
@@ -3343,8 +3378,8 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
             HIP_TRY(hipGetLastError());
             if ((rc = prof_mark(*D, s, RDST_STAGE_ROUTE))) return rc;
             rc = launch_local_sort<K>(keys, tmp, reinterpret_cast<const uint32_t*>(ws + L.off_bstart), plan, D->err_dev, km,
-                                      reinterpret_cast<uint32_t*>(ws + L.off_fblist), reinterpret_cast<uint32_t*>(ws + L.off_err) + 3, slots,
-                                      D->cus, s, cursor_b, (uint32_t)local_tile(4));
+                                      reinterpret_cast<uint32_t*>(ws + L.off_fblist), reinterpret_cast<uint32_t*>(ws + L.off_err) + 3, slots16,
+                                      D->cus, s, cursor_b, slot_cap, slots);
             if (rc) return rc;
             if ((rc = prof_mark(*D, s, RDST_STAGE_LOCAL))) return rc;
             // the LSD route's status rows, if the route fell that way
@@ -3686,7 +3721,8 @@ int rdst_hip_set_hybrid(int enabled, uint64_t min_len) {
     g_tuning.halves = enabled != 3;      // 3: counting K4 reading whole keys (no 16-bit hand-off) (A/B, tests)
     g_tuning.presample = enabled != 5;   // 5: no sample before K1h: every hybrid-eligible sort counts all its keys' prefixes first (tests)
     g_tuning.wide2 = enabled != 6;       // 6: 8-byte keys with the one-block-per-CU form of K4 (A/B, tests)
-    g_tuning.atomic_route = enabled == 1;  // 1: the default (4-byte keys try the atomic route first); 2..7: the K1h hybrid route for every key width (7: with the default forms of K4)
+    g_tuning.atomic_route = enabled == 1 || enabled == 8;  // 1: the default (4- and 8-byte keys try the atomic route first); 2..7: the K1h hybrid route for every key width (7: with the default forms of K4)
+    g_tuning.atomic_wide = enabled != 8;   // 8: the atomic route for 4-byte keys only, 8-byte keys on the K1h hybrid route (A/B, tests)
     g_tuning.hybrid_min_len = min_len ? min_len : (1ull << 28);
     return RDST_OK;
 }

@@ -462,13 +462,16 @@ def profile_run(run: int, levels: int):
 
 
 def set_hybrid(enabled=True, min_len=0):
-    """Route choice knob (rdst_hip_set_hybrid): consider the byte-saving routes (atomic for 4-byte keys, hybrid for 8-byte keys) for
-    sorts of at least `min_len` keys (0 = built-in threshold); enabled == 7: the hybrid (K1h) route for 4-byte keys too.  enabled == 2: the hybrid route with the generic ranked local sort for 4-byte keys too; 3: counting local sort fed with whole keys (no 16-bit hand-off)."""
-    _lib.check(_lib.load().rdst_hip_set_hybrid(int(enabled) if enabled in (2, 3, 5, 6, 7) else int(bool(enabled)), int(min_len)))
+    """Route choice knob (rdst_hip_set_hybrid): consider the byte-saving routes for sorts of at least `min_len` keys (0 = the
+    built-in threshold).  True / 1: the default — 4- and 8-byte keys try the atomic route.  False / 0: LSD only.  A/B and
+    test modes: 7 the K1h hybrid route for every width; 2 the same with the generic ranked K4; 3 counting K4 fed with whole
+    keys (no 16-bit hand-off); 5 no presample; 6 8-byte keys with the one-block-per-CU K4; 8 the atomic route for 4-byte
+    keys only (8-byte keys on the hybrid route)."""
+    _lib.check(_lib.load().rdst_hip_set_hybrid(int(enabled) if enabled in (2, 3, 5, 6, 7, 8) else int(bool(enabled)), int(min_len)))
 
 
 def last_route(device=None) -> str:
-    """'lsd' or 'hybrid': the route the most recent sort on the current stream's device took."""
+    """'lsd', 'hybrid' or 'atomic': the route the most recent sort on the current stream's device took."""
     import torch
     lib = _lib.load()
     r = ctypes.c_uint32(0)

@@ -34,11 +34,12 @@ def _is_sorted(torch, m, chunk=1 << 27):
 
 
 @pytest.mark.parametrize("name,itype_name,seed,route", [("uint32", "int32", 0x5D570002, "atomic"), ("uint32", "int32", 0x5D570002, "hybrid"),
-                                                         ("uint32", "int32", 0x5D570002, "lsd"), ("uint64", "int64", 0x5D570003, "hybrid"),
-                                                         ("float32", "int32", 0x5D570004, "atomic"), ("float64", "int64", 0x5D570007, "hybrid")])
+                                                         ("uint32", "int32", 0x5D570002, "lsd"), ("uint64", "int64", 0x5D570003, "atomic"),
+                                                         ("uint64", "int64", 0x5D570003, "hybrid"),
+                                                         ("float32", "int32", 0x5D570004, "atomic"), ("float64", "int64", 0x5D570007, "atomic")])
 def test_one_billion_keys(gpu, name, itype_name, seed, route):
-    """`route`: uniform 10^9-key slices take the atomic (4-byte keys) / hybrid (8-byte keys) route by the device's own choice
-    (asserted); the hybrid route for 4-byte keys and the LSD route — every skewed input's route — are forced once at full size too."""
+    """`route`: uniform 10^9-key slices take the atomic route by the device's own choice (asserted); the K1h hybrid route and
+    the LSD route — every skewed input's route — are forced once at full size too."""
     import torch
     itype = getattr(torch, itype_name)
     src = _gen(torch, N, itype, seed)

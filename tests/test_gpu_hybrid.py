@@ -14,12 +14,13 @@ pytestmark = pytest.mark.gpu
 TILE = {4: 16896, 8: 16384}  # K4 tile = largest bucket the hybrid route accepts
 
 
-@pytest.fixture(params=["count", "count_whole_keys", "ranked", "wide_one_block", "atomic"])
+@pytest.fixture(params=["count", "count_whole_keys", "ranked", "wide_one_block", "atomic", "atomic_4_only"])
 def hybrid(gpu, request):
     """the forms of K4 for 4-byte keys: the counting sort by value fed with the 16-bit halves pass L-1 leaves in the
     workspace ("count": the K1h hybrid route; 8-byte keys: two 512-thread blocks per CU, or — "wide_one_block" — one of 1024), the same fed with whole keys, the generic ranked passes (the fallback for buckets whose counters overflow), and "atomic": the library's default, in which
-    4-byte keys take the atomic route (MSD passes that claim space, no counting read) and 8-byte keys the hybrid one"""
-    mode = {"count": 7, "count_whole_keys": 3, "ranked": 2, "wide_one_block": 6, "atomic": True}[request.param]
+    4- and 8-byte keys take the atomic route (MSD passes that claim space, no counting read; "atomic_4_only": 8-byte keys on
+    the hybrid one)"""
+    mode = {"count": 7, "count_whole_keys": 3, "ranked": 2, "wide_one_block": 6, "atomic": True, "atomic_4_only": 8}[request.param]
     gpu.set_hybrid(mode, min_len=1)   # consider the route at every length (default: 2^28 and up)
     gpu._test_mode = request.param
     yield gpu
@@ -28,10 +29,11 @@ def hybrid(gpu, request):
 
 
 def _fast_route(rdst, route, dtype, strict=True):
-    """the route a sort that CAN leave the LSD route must have taken: "hybrid" — except in the "atomic" mode of the fixture, where
-    4-byte keys take the atomic route; an input whose top byte is far from uniform overflows that route's areas and falls to LSD
-    (strict=False: both are fine)"""
-    if getattr(rdst, "_test_mode", "") == "atomic" and np.dtype(dtype).itemsize == 4:
+    """the route a sort that CAN leave the LSD route must have taken: "hybrid" — except in the "atomic" modes of the fixture,
+    where 4-byte (and, in "atomic", 8-byte) keys take the atomic route; an input whose top byte is far from uniform overflows
+    that route's areas and falls to LSD (strict=False: both are fine)"""
+    mode, nb = getattr(rdst, "_test_mode", ""), np.dtype(dtype).itemsize
+    if (mode == "atomic" and nb in (4, 8)) or (mode == "atomic_4_only" and nb == 4):
         return route == "atomic" or (not strict and route == "lsd")
     return route == "hybrid"
 
@@ -178,7 +180,7 @@ def test_fast_rank_selftest_and_ballot_modes_agree(hybrid):
         got, route = _sort(hybrid, a)
         assert route in ("hybrid", "atomic", "lsd") and same_bits(got, exp_a), mode
         got, route = _sort(hybrid, b)
-        assert route == "hybrid" and same_bits(got, exp_b), mode
+        assert _fast_route(hybrid, route, "uint64") and same_bits(got, exp_b), mode
     hybrid.set_tuning()
 
 
