@@ -107,6 +107,7 @@ struct Plan {
     uint32_t route;                   // ROUTE_LSD or ROUTE_HYBRID (decided on the device by route_kernel)
     uint32_t local_sort;              // hybrid route and the slice is not already sorted: K4 runs
     uint32_t gross_skew;              // a sample of the keys already rules the hybrid route out (presample_kernel): K1h returns at once
+    uint32_t top_skew;                // the sample's top bytes are far from uniform: the atomic route's areas would overflow, its passes return at once
     uint32_t sorted_known;            // K1h swept the whole slice and met no inversion: K1 need not read it again (K2 turns every pass off)
 };
 
@@ -422,17 +423,20 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const K* __restrict_
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t PRESAMPLE_KEYS = 8192;  // 65 536 spread-out keys cost 0.17 ms (a TLB miss each); 8 192 in one batch of loads: ~0.01 ms
 constexpr uint64_t PRESAMPLE_MIN_LEN = 1ull << 28;  // below it a full tile expects more hits than 8-bit counters and a small limit allow
-constexpr size_t presample_lds_bytes() { return H16_BINS + 16; }
+constexpr size_t presample_lds_bytes() { return H16_BINS + 16 + 4 * RADIX; }
+constexpr uint32_t PRESAMPLE_TOP_LIMIT = 2 * PRESAMPLE_KEYS / RADIX;  // twice a top byte's share of the sample (Poisson(32) >= 64: 2e-7)
 
 template <typename K, bool MAPPED>
 __global__ __launch_bounds__(1024) void presample_kernel(const K* __restrict__ keys, uint64_t n, K neg, K pos, Plan* __restrict__ plan, uint32_t limit) {
     constexpr int W = sizeof(K) * 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* s_c = reinterpret_cast<uint32_t*>(smem);               // 65 536 8-bit counters, four per word
-    uint32_t* s_skew = reinterpret_cast<uint32_t*>(smem + H16_BINS);
+    uint32_t* s_skew = reinterpret_cast<uint32_t*>(smem + H16_BINS);   // [0] a prefix over the limit, [1] a top byte over its limit
+    uint32_t* s_top = reinterpret_cast<uint32_t*>(smem + H16_BINS + 16); // [256] the sample's top bytes
     const int tid = threadIdx.x;
     for (int i = tid; i < H16_BINS / 4; i += 1024) s_c[i] = 0;
-    if (tid == 0) *s_skew = 0;
+    if (tid < RADIX) s_top[tid] = 0;
+    if (tid < 2) s_skew[tid] = 0;
     __syncthreads();
     const uint64_t step = n / PRESAMPLE_KEYS;
     bool skew = false;
@@ -448,11 +452,17 @@ __global__ __launch_bounds__(1024) void presample_kernel(const K* __restrict__ k
             const uint32_t sh = (b & 3u) * 8u;
             const uint32_t old = atomicAdd(&s_c[b >> 2], 1u << sh);
             skew |= ((old >> sh) & 0xFFu) + 1u >= limit;  // limit <= 64: the flag fires long before a counter could carry
+            atomicAdd(&s_top[b >> 8], 1u);
         }
     }
-    if (skew) *s_skew = 1;
+    if (skew) s_skew[0] = 1;
     __syncthreads();
-    if (tid == 0 && *s_skew) plan->gross_skew = 1;
+    // the atomic route's areas hold a top byte's share of the keys plus a percent: a byte with twice its share of the sample
+    // would overflow its areas a third of the way through pass A — that route is not tried (the hybrid one is)
+    if (tid < RADIX && s_top[tid] >= PRESAMPLE_TOP_LIMIT) s_skew[1] = 1;
+    __syncthreads();
+    if (tid == 0 && s_skew[0]) plan->gross_skew = 1;
+    if (tid == 0 && s_skew[1]) plan->top_skew = 1;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -482,6 +492,7 @@ __global__ __launch_bounds__(HIST_THREADS) void hist16_kernel(const K* __restric
                                                               const Plan* __restrict__ plan) {
     constexpr int W = sizeof(K) * 8;
     if (plan->gross_skew) return;  // the sample ruled the hybrid route out: K1 will count (and look for inversions) instead
+    if (plan->route == ROUTE_ATOMIC) return;  // the atomic route was tried first and took the sort
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* s_h = reinterpret_cast<uint32_t*>(smem);
     __shared__ unsigned long long s_sum;
@@ -626,6 +637,7 @@ struct RouteArgs {
 __global__ __launch_bounds__(1024) void route_kernel(RouteArgs a) {
     __shared__ uint32_t s_wsum[16], s_wmax[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (a.plan->route == ROUTE_ATOMIC) return;  // tried first, and it took the sort (msd_finish_kernel): nothing to decide
     uint32_t c[64];
     const uint4* src = reinterpret_cast<const uint4*>(a.h16) + (size_t)tid * 16;
 #pragma unroll
@@ -701,8 +713,8 @@ struct MsdFinishArgs {
 __global__ __launch_bounds__(1024) void msd_finish_kernel(MsdFinishArgs a) {
     __shared__ uint32_t s_wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool sorted = a.allow_skip && *a.inversion == 0 && a.plan->gross_skew == 0 && *a.overflow == 0;
-    const bool ok = a.plan->gross_skew == 0 && *a.overflow == 0;
+    const bool ok = a.plan->gross_skew == 0 && a.plan->top_skew == 0 && *a.overflow == 0;
+    const bool sorted = ok && a.allow_skip && *a.inversion == 0;
     if (tid == 0) {
         a.plan->route = ok ? ROUTE_ATOMIC : ROUTE_LSD;
         a.plan->local_sort = ok && !sorted ? 1u : 0u;
@@ -1535,7 +1547,8 @@ __global__ __launch_bounds__(NWAVES * 64, (2 * NWAVES + 3) / 4) void msd_scatter
     static_assert(!HALVES || (SECOND && sizeof(K) == 4), "halves: the second pass of 4-byte keys");
     constexpr int BLOCK = NWAVES * 64, TILE = BLOCK * KPT;
     constexpr uint32_t SLOT_UNIT = (uint32_t)sizeof(K);
-    if (plan->gross_skew || *overflow) return;  // the sample or an earlier pass already gave the route up
+    // the sample or an earlier tile already gave the route up (a coherent load: the flag is raised by blocks on other XCDs)
+    if (plan->gross_skew || plan->top_skew || ld_relaxed<uint32_t>(overflow)) return;
     if (SECOND && *inversion == 0) return;      // pass A met no inversion: the slice is sorted, nothing to do
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* wave_hist = reinterpret_cast<uint32_t*>(smem);                           // [NWAVES][256]
@@ -1673,7 +1686,7 @@ __global__ __launch_bounds__(NWAVES * 64, (2 * NWAVES + 3) / 4) void msd_scatter
             // 1.555 ms against 1.554 with XCD-local workgroup-scope claims on per-XCD counters.)
             got = atomicAdd(&cursor[where], pub);
             if (got + pub > dst_cap) {  // no room: give the route up, store nothing of this tile
-                atomicOr(overflow, 1u);
+                if (ld_relaxed<uint32_t>(overflow) == 0) atomicOr(overflow, 1u);  // (look first: thousands of tiles get here, see the inversion flag)
                 s_misc[1] = 1;
             }
         }
@@ -2071,6 +2084,7 @@ __global__ __launch_bounds__(NWAVES * 64, (sizeof(K) <= 4 ? 2 : 1) * NWAVES / 4)
     uint32_t* __restrict__ err, K neg, K pos, uint32_t flags, const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count,
     const uint16_t* __restrict__ src16, const uint32_t* __restrict__ slot_count, uint32_t slot_cap, const K* __restrict__ alt_src) {
     if (!plan->local_sort) return;
+    if (plan->route != ROUTE_ATOMIC) { slot_count = nullptr; alt_src = nullptr; }  // the hybrid route's buckets lie at their final place
     K* __restrict__ buf = plan->result_in_tmp ? buf_tmp : buf_keys;
     if (list == nullptr) {
         const uint32_t bucket = blockIdx.x;
@@ -2124,6 +2138,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 8 : 6) void local_count_sort
     constexpr int LOG_VPT = BLOCK == 1024 ? 6 : (BLOCK == 512 ? 7 : 8);
     static_assert((1 << LOG_VPT) == VPT, "block size");
     if (!plan->local_sort) return;
+    if (plan->route != ROUTE_ATOMIC) slot_count = nullptr;  // the hybrid route's buckets lie at their final place (src16: position for position)
     uint32_t* __restrict__ buf = plan->result_in_tmp ? buf_tmp : buf_keys;
     const uint32_t bucket = blockIdx.x;
     const uint32_t start = bstart[bucket], cnt = slot_count ? slot_count[bucket] : bstart[bucket + 1] - start;
@@ -2138,8 +2153,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 8 : 6) void local_count_sort
         }
         return;
     }
-    if (cnt > (uint32_t)COUNT_TILE) {
-        if (tid == 0) atomicOr(err, ERR_LOCAL_OVERFLOW);
+    if (cnt > (uint32_t)COUNT_TILE) {  // more than this kernel stages: the expanding kernel below takes it (any bucket below 65 536 keys)
+        if (tid == 0) list[atomicAdd(list_count, 1u)] = bucket;
         return;
     }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -2233,6 +2248,250 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 8 : 6) void local_count_sort
             const uint32_t m = top | (uint32_t)out16[idx];
             tdst[idx] = MAPPED ? unmap_key<uint32_t>(m, neg, pos) : m;
         }
+    }
+}
+
+// K4 for the buckets the kernel above hands on (4-byte keys): more keys than its tile, or a value seen 16 times.
+// Counting sort by value again, but the keys are only COUNTED — a bucket's keys are its index and their low 16 bits,
+// so the sorted bucket is the count table written out: value v, count[v] times.  Nothing is staged, ranked or
+// moved, the bucket may hold anything below 65 536 keys (16-bit counters cannot carry then, whatever the keys are)
+// and duplicates cost nothing extra.
+//   count     one LDS add per key on 65 536 16-bit counters (128 KiB; a wave whose 64 keys are one value adds once)
+//   scan      thread t owns 64 consecutive values (32 words, stored word-major so the sweep is conflict-free) and
+//             replaces the counts by exclusive prefixes
+//   expand    output position i holds the largest v with prefix[v] <= i: a 16-step search of the table, then one
+//             coalesced store of (bucket << 16 | v) with the key map undone
+// One block per CU walks the list.  Twice the LDS reads per key of the kernel above; it runs on what that one refuses:
+// skewed low halves (a bucket of 15 000 keys over 256 distinct values) and buckets of up to four tiles.
+constexpr int EXPAND_THREADS = 1024;
+constexpr uint32_t EXPAND_MAX = 65535;  // keys per bucket
+constexpr int EXPAND_WORDS = H16_BINS / 2 + H16_BINS / 64;  // two counters per word, one pad word after every 32
+constexpr size_t expand_lds_bytes() { return 4 * (size_t)EXPAND_WORDS + 128; }
+
+template <bool MAPPED, bool FROM16>
+__global__ __launch_bounds__(EXPAND_THREADS) void local_expand_sort_kernel(
+    uint32_t* __restrict__ buf_keys, uint32_t* __restrict__ buf_tmp, const uint16_t* __restrict__ src16, const uint32_t* __restrict__ bstart,
+    const Plan* __restrict__ plan, uint32_t* __restrict__ err, uint32_t neg, uint32_t pos, const uint32_t* __restrict__ list,
+    const uint32_t* __restrict__ list_count, const uint32_t* __restrict__ slot_count, uint32_t slot_cap) {
+    constexpr int BLOCK = EXPAND_THREADS, WPT = H16_BINS / 2 / BLOCK;  // 32 words of two counters per thread
+    if (!plan->local_sort) return;
+    if (plan->route != ROUTE_ATOMIC) slot_count = nullptr;
+    uint32_t* __restrict__ buf = plan->result_in_tmp ? buf_tmp : buf_keys;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // word w = v / 2 lives at w + w / 32: thread t's 32 consecutive words start at 33 t (the scan's sweep is conflict-free) and
+    // neighbouring values stay neighbours (a bucket whose low halves differ in a few bits only — what this kernel is for —
+    // would hit two or four banks with a thread-major table)
+    uint32_t* tab = reinterpret_cast<uint32_t*>(smem);
+    uint32_t* s_wsum = reinterpret_cast<uint32_t*>(smem + 4 * (size_t)EXPAND_WORDS);  // [16]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    auto word_of = [](uint32_t v) -> uint32_t { return (v >> 1) + (v >> 6); };
+    const uint32_t total = *list_count;
+    for (uint32_t e = blockIdx.x; e < total; e += gridDim.x) {
+        const uint32_t bucket = list[e];
+        const uint32_t start = bstart[bucket], cnt = slot_count ? slot_count[bucket] : bstart[bucket + 1] - start;
+        const uint32_t soff = slot_count ? bucket * slot_cap : start;
+        if (cnt > EXPAND_MAX) {  // the route checks every bucket against this bound before it sends any here
+            if (tid == 0) atomicOr(err, ERR_LOCAL_OVERFLOW);
+            continue;
+        }
+        for (int i = tid; i < EXPAND_WORDS; i += BLOCK) tab[i] = 0;
+        __syncthreads();
+        constexpr int U = 8;  // keys in flight per thread: the loads of a batch are issued together, so are the searches below
+        for (uint32_t base = 0; base < cnt; base += BLOCK * U) {  // wave-uniform trip count
+            uint32_t v[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const uint32_t idx = base + (uint32_t)j * BLOCK + (uint32_t)tid;
+                const uint32_t at = idx < cnt ? idx : cnt - 1;
+                if constexpr (FROM16) v[j] = src16[soff + at];
+                else v[j] = buf[start + at];
+            }
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const uint32_t idx = base + (uint32_t)j * BLOCK + (uint32_t)tid;
+                const bool valid = idx < cnt;
+                const uint32_t x = FROM16 ? v[j] : ((MAPPED ? map_key<uint32_t>(v[j], neg, pos) : v[j]) & 0xFFFFu);
+                const uint32_t x0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
+                if (__all((int)(valid && x == x0)) != 0) {  // 64 keys of one value: one add, not 64 on one address
+                    if (lane == 0) atomicAdd(&tab[word_of(x0)], 64u << ((x0 & 1u) * 16u));
+                } else if (valid) {
+                    atomicAdd(&tab[word_of(x)], 1u << ((x & 1u) * 16u));
+                }
+            }
+        }
+        __syncthreads();
+        {
+            uint32_t run = 0;
+#pragma unroll
+            for (int k = 0; k < WPT; ++k) {
+                const uint32_t w = tab[(WPT + 1) * tid + k];
+                run += (w & 0xFFFFu) + (w >> 16);
+            }
+            uint32_t incl = run;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t y = __shfl_up(incl, o);
+                if (lane >= o) incl += y;
+            }
+            if (lane == 63) s_wsum[wave] = incl;
+            __syncthreads();
+            uint32_t below = incl - run;
+#pragma unroll
+            for (int x = 0; x < BLOCK / 64; ++x)
+                if (x < wave) below += s_wsum[x];
+#pragma unroll
+            for (int k = 0; k < WPT; ++k) {  // (every prefix is at most cnt <= 65 535: 16 bits hold it)
+                const uint32_t w = tab[(WPT + 1) * tid + k];
+                const uint32_t lo = below, hi = below + (w & 0xFFFFu);
+                below = hi + (w >> 16);
+                tab[(WPT + 1) * tid + k] = lo | (hi << 16);
+            }
+        }
+        __syncthreads();
+        const uint32_t top = bucket << 16;
+        for (uint32_t base = 0; base < cnt; base += BLOCK * U) {
+            uint32_t v[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) v[j] = 0;  // prefix[0] == 0 <= every position
+#pragma unroll
+            for (int b = 15; b >= 0; --b) {
+#pragma unroll
+                for (int j = 0; j < U; ++j) {  // (positions past the bucket's end search too, and find its last value: harmless)
+                    const uint32_t idx = base + (uint32_t)j * BLOCK + (uint32_t)tid;
+                    const uint32_t c = v[j] | (1u << b);
+                    const uint32_t p = (tab[word_of(c)] >> ((c & 1u) * 16u)) & 0xFFFFu;
+                    if (p <= idx) v[j] = c;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const uint32_t idx = base + (uint32_t)j * BLOCK + (uint32_t)tid;
+                const uint32_t m = top | v[j];
+                if (idx < cnt) buf[start + idx] = MAPPED ? unmap_key<uint32_t>(m, neg, pos) : m;
+            }
+        }
+        __syncthreads();  // the next bucket clears the table
+    }
+}
+
+// Between the two: buckets of up to 17 408 keys whose low halves repeat (what the 4-bit counters of the first kernel
+// refuse).  The first kernel's scheme — returning add, scan, place, stage, store; keys in registers throughout — on the
+// 16-bit counters and the padded table of the expanding kernel: a counter holds any count a bucket of this size can
+// produce, so every bucket that fits the registers is sorted here whatever its keys are, at ~5 LDS operations per key
+// instead of the expanding kernel's ~20.  One block per CU walks the list (the table fills the LDS) and hands buckets
+// over its tile to a second list, for the expanding kernel.
+constexpr int COUNT16_THREADS = 1024, COUNT16_KPT = 17;
+constexpr int COUNT16_TILE = COUNT16_THREADS * COUNT16_KPT;  // 17 408 >= the route's tile (16 896)
+static_assert(COUNT16_TILE >= COUNT_TILE && 2 * (size_t)COUNT16_TILE <= 4 * (size_t)EXPAND_WORDS, "staging aliases the table");
+
+template <bool MAPPED, bool FROM16>
+__global__ __launch_bounds__(COUNT16_THREADS) void local_count16_sort_kernel(
+    uint32_t* __restrict__ buf_keys, uint32_t* __restrict__ buf_tmp, const uint16_t* __restrict__ src16, const uint32_t* __restrict__ bstart,
+    const Plan* __restrict__ plan, uint32_t neg, uint32_t pos, const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count,
+    uint32_t* __restrict__ list2, uint32_t* __restrict__ list2_count, const uint32_t* __restrict__ slot_count, uint32_t slot_cap) {
+    constexpr int BLOCK = COUNT16_THREADS, KPT = COUNT16_KPT, WPT = H16_BINS / 2 / BLOCK;
+    if (!plan->local_sort) return;
+    if (plan->route != ROUTE_ATOMIC) slot_count = nullptr;
+    uint32_t* __restrict__ buf = plan->result_in_tmp ? buf_tmp : buf_keys;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* tab = reinterpret_cast<uint32_t*>(smem);   // 65 536 16-bit counters, then prefixes (layout: local_expand_sort_kernel)
+    uint16_t* out16 = reinterpret_cast<uint16_t*>(smem); // [cnt] sorted low halves (aliases the table, later)
+    uint32_t* s_wsum = reinterpret_cast<uint32_t*>(smem + 4 * (size_t)EXPAND_WORDS);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    auto word_of = [](uint32_t v) -> uint32_t { return (v >> 1) + (v >> 6); };
+    const uint32_t total = *list_count;
+    for (uint32_t e = blockIdx.x; e < total; e += gridDim.x) {
+        const uint32_t bucket = list[e];
+        const uint32_t start = bstart[bucket], cnt = slot_count ? slot_count[bucket] : bstart[bucket + 1] - start;
+        const uint32_t soff = slot_count ? bucket * slot_cap : start;
+        if (cnt > (uint32_t)COUNT16_TILE) {
+            if (tid == 0) list2[atomicAdd(list2_count, 1u)] = bucket;
+            continue;
+        }
+        uint32_t kv[KPT];
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const uint32_t idx = (uint32_t)tid + i * BLOCK;
+            const uint32_t at = idx < cnt ? idx : cnt - 1;
+            if constexpr (FROM16) kv[i] = src16[soff + at];
+            else kv[i] = buf[start + at];
+        }
+        {
+            uint4* t4 = reinterpret_cast<uint4*>(tab);
+            const uint4 z = {0, 0, 0, 0};
+            for (int i = tid; i < EXPAND_WORDS / 4; i += BLOCK) t4[i] = z;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const uint32_t idx = (uint32_t)tid + i * BLOCK;
+            const bool valid = idx < cnt;  // wave-uniform except in the bucket's last wave
+            const uint32_t v = FROM16 ? kv[i] : ((MAPPED ? map_key<uint32_t>(kv[i], neg, pos) : kv[i]) & 0xFFFFu);
+            const uint32_t sh = (v & 1u) * 16u;
+            const uint32_t v0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+            uint32_t mine = 0;
+            if (__all((int)(valid && v == v0)) != 0) {  // 64 keys of one value: one add for the wave, the lanes take consecutive indices
+                uint32_t old = 0;
+                if (lane == 0) old = atomicAdd(&tab[word_of(v0)], 64u << sh);
+                mine = (((uint32_t)__builtin_amdgcn_readfirstlane((int)old) >> sh) & 0xFFFFu) + (uint32_t)lane;
+            } else if (valid) {
+                mine = (atomicAdd(&tab[word_of(v)], 1u << sh) >> sh) & 0xFFFFu;
+            }
+            kv[i] = v | (mine << 16);
+        }
+        __syncthreads();
+        {
+            uint32_t run = 0;
+#pragma unroll
+            for (int k = 0; k < WPT; ++k) {
+                const uint32_t w = tab[(WPT + 1) * tid + k];
+                run += (w & 0xFFFFu) + (w >> 16);
+            }
+            uint32_t incl = run;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t y = __shfl_up(incl, o);
+                if (lane >= o) incl += y;
+            }
+            if (lane == 63) s_wsum[wave] = incl;
+            __syncthreads();
+            uint32_t below = incl - run;
+#pragma unroll
+            for (int x = 0; x < BLOCK / 64; ++x)
+                if (x < wave) below += s_wsum[x];
+#pragma unroll
+            for (int k = 0; k < WPT; ++k) {
+                const uint32_t w = tab[(WPT + 1) * tid + k];
+                const uint32_t lo = below, hi = below + (w & 0xFFFFu);
+                below = hi + (w >> 16);
+                tab[(WPT + 1) * tid + k] = lo | (hi << 16);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const uint32_t v = kv[i] & 0xFFFFu;
+            const uint32_t slot = ((tab[word_of(v)] >> ((v & 1u) * 16u)) & 0xFFFFu) + (kv[i] >> 16);
+            kv[i] = v | (slot << 16);
+        }
+        __syncthreads();  // the table is dead: its space becomes the output staging
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const uint32_t idx = (uint32_t)tid + i * BLOCK;
+            if (idx < cnt) out16[kv[i] >> 16] = (uint16_t)kv[i];
+        }
+        __syncthreads();
+        uint32_t* tdst = buf + start;
+        const uint32_t top = bucket << 16;
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const uint32_t idx = (uint32_t)tid + i * BLOCK;
+            if (idx < cnt) {
+                const uint32_t m = top | (uint32_t)out16[idx];
+                tdst[idx] = MAPPED ? unmap_key<uint32_t>(m, neg, pos) : m;
+            }
+        }
+        __syncthreads();  // the next bucket clears the table
     }
 }
 
@@ -2411,6 +2670,7 @@ __global__ __launch_bounds__(WIDE2_THREADS, 8) void local_wide2_sort_kernel(
     constexpr int HALF = TILE / 2;
     static_assert((size_t)HALF * 8 <= 32768 + 8192 + 2 * (size_t)TILE, "output staging fits the dead tables");
     if (!plan->local_sort) return;
+    if (plan->route != ROUTE_ATOMIC) src_slots = nullptr;  // the hybrid route's buckets lie at their final place
     uint64_t* __restrict__ buf = plan->result_in_tmp ? buf_tmp : buf_keys;
     const uint32_t bucket = blockIdx.x;
     const uint32_t start = bstart[bucket], cnt = src_slots ? slot_count[bucket] : bstart[bucket + 1] - start;
@@ -2646,9 +2906,10 @@ __global__ __launch_bounds__(256) void stream_read_kernel(const uint4* __restric
 }
 
 // Status rows of the levels only the LSD route uses: cleared after the route decision, and only if it fell that way
+// (`unless_atomic`: behind a failed atomic route the hybrid route's two passes need their rows too: clear unless the atomic route took the sort)
 __global__ __launch_bounds__(256) void clear_unless_hybrid_kernel(const Plan* __restrict__ plan, uint4* __restrict__ a, uint64_t na, uint4* __restrict__ b,
-                                                                  uint64_t nb) {
-    if (plan->route != ROUTE_LSD) return;
+                                                                  uint64_t nb, uint32_t unless_atomic) {
+    if (unless_atomic ? plan->route == ROUTE_ATOMIC : plan->route != ROUTE_LSD) return;
     const uint64_t stride = (uint64_t)gridDim.x * 256;
     const uint4 z = {0, 0, 0, 0};
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < na; i += stride) a[i] = z;
@@ -2784,6 +3045,8 @@ struct Tuning {
     bool presample = true;              // a 65 536-key sample before K1h: gross skew goes straight to the LSD route
     bool wide2 = true;                  // 8-byte keys: K4 as two 512-thread blocks per CU (false: one 1024-thread block)
     bool atomic_route = true;           // 4-byte keys: try ROUTE_ATOMIC (no counting read) before anything else
+    bool chain_routes = true;           // behind a failed atomic route try the hybrid route before the LSD one
+    bool expand = true;                 // 4-byte keys: buckets the counting K4 refuses go to the expanding one (any bucket below 65 536 keys)
     bool atomic_wide = true;            // ROUTE_ATOMIC for 8-byte keys too (whole keys in the slots)
     bool persist_fallback = true;       // behind the atomic route the LSD passes run as persistent blocks (cheap to skip)
     uint64_t hybrid_min_len = 1ull << 28;  // below this the buckets are too small for one workgroup each to pay off
@@ -2833,7 +3096,7 @@ struct Layout {
     uint32_t levels, tile, status_bytes;  // status_bytes: 4 or 8 per word
     uint64_t tiles;
     size_t off_err, off_tickets, off_plan, off_hpos, off_hpair, off_h16, off_hpos16, off_status, off_status_near, zero_bytes, off_hist, off_base,
-        off_cbase, off_chains, off_bstart, off_fblist, off_halves, off_cursor_a, off_cursor_b, off_msd_a, total;
+        off_cbase, off_chains, off_bstart, off_fblist, off_fblist2, off_halves, off_cursor_a, off_cursor_b, off_msd_a, total;
     uint32_t msd_cap_a, msd_slices;  // ROUTE_ATOMIC: keys an area of pass A holds; areas per top digit
 };
 
@@ -2852,7 +3115,7 @@ Layout make_layout(uint64_t n, uint32_t elem_bytes, uint32_t levels, int cfg, ui
     L.tiles = n / L.tile + CHAINS + 2;  // status rows per level: every chain may end and begin on partial tiles
     L.status_bytes = n < (1ull << 30) ? 4 : 8;  // an inclusive prefix can reach n
     size_t o = 0;
-    L.off_err = o; o += 64;  // cleared flags of one sort: [1] inversion seen, [2] a K1h counter overflowed, [3] length of the local-sort fallback list (the error word itself lives in DeviceState::err_dev)
+    L.off_err = o; o += 64;  // cleared flags of one sort: [1] inversion seen, [2] a K1h counter overflowed, [3] length of K4's first hand-on list, [4] an area or a slot of the atomic route overflowed, [5] length of K4's second list (the error word itself lives in DeviceState::err_dev)
     o = align_up(o, 128);
     L.off_tickets = o; o += sizeof(uint32_t) * MAX_LEVELS * TICKET_ROW;  // per chain + mask of chains handed out, a line each
     L.off_plan = o; o += align_up(sizeof(Plan), 16);
@@ -2872,7 +3135,8 @@ Layout make_layout(uint64_t n, uint32_t elem_bytes, uint32_t levels, int cfg, ui
     L.off_chains = o; o += sizeof(LevelChains) * (size_t)levels;
     o = align_up(o, 16);
     L.off_bstart = o; o += sizeof(uint32_t) * ((size_t)H16_BINS + 4);     // hybrid route: bucket starts
-    L.off_fblist = o; o += sizeof(uint32_t) * (size_t)H16_BINS;           // buckets left to the generic local sort (count: header word 3)
+    L.off_fblist = o; o += sizeof(uint32_t) * (size_t)H16_BINS;           // buckets the first K4 kernel hands on (count: header word 3)
+    L.off_fblist2 = o; o += sizeof(uint32_t) * (size_t)H16_BINS;          // and those the second one hands on (count: header word 5)
     o = align_up(o, 256);
     L.off_halves = o;                                                       // hybrid route, 4-byte keys: low halves between pass L-1 and K4
     if (want_halves && !want_msd) o += align_up(sizeof(uint16_t) * n, 256);
@@ -2973,8 +3237,9 @@ bool atomic_eligible(uint64_t n, size_t key_bytes, int cfg) {
 }
 
 bool hybrid_eligible(uint64_t n, size_t key_bytes) {
-    return g_tuning.hybrid && (key_bytes == 4 || key_bytes == 8) && n >= g_tuning.hybrid_min_len &&
-           n <= (uint64_t)H16_BINS * local_tile(key_bytes) && n < (1ull << 32);
+    const uint64_t cap = key_bytes == 4 && g_tuning.count_sort && g_tuning.expand ? EXPAND_MAX : (uint64_t)local_tile(key_bytes);
+    return g_tuning.hybrid && (key_bytes == 4 || key_bytes == 8) && n >= g_tuning.hybrid_min_len && n <= (uint64_t)H16_BINS * cap &&
+           n < (1ull << 32);
 }
 
 // hipFuncSetAttribute acts on the CURRENT device's copy of the function: remember (device, kernel) -> bytes
@@ -3048,10 +3313,11 @@ int launch_presample(const K* keys, uint64_t n, KeyMap km, Plan* plan, hipStream
 // K1h: the hybrid route's 65 536-bin count (same grid and pieces as K1)
 template <typename K>
 int launch_hist16(const K* keys, uint64_t n, uint32_t blocks, KeyMap km, uint32_t* h16, unsigned long long* hpos16, uint32_t* inversion,
-                  uint32_t* overflow, Plan* plan, hipStream_t s) {
+                  uint32_t* overflow, Plan* plan, hipStream_t s, bool sample_first = true) {
     const bool aligned = (reinterpret_cast<uintptr_t>(keys) & 15u) == 0;
     const bool mapped = km.neg != 0 || km.pos != 0;
-    if (int rc = launch_presample<K>(keys, n, km, plan, s)) return rc;
+    if (sample_first)
+        if (int rc = launch_presample<K>(keys, n, km, plan, s)) return rc;
     constexpr int V = 16 / sizeof(K);
     constexpr size_t lds = (size_t)H16_WORDS * sizeof(uint32_t);
 #define RDST_H16(VEC, MAPPED)                                                                                              \
@@ -3076,7 +3342,7 @@ constexpr int COUNT_THREADS = RDST_COUNT_THREADS;
 template <typename K>
 int launch_local_sort(K* keys, K* tmp, const uint32_t* bstart, const Plan* plan, uint32_t* err, KeyMap km, uint32_t* list,
                       uint32_t* list_count, const uint16_t* src16, int cus, hipStream_t s, const uint32_t* slot_count = nullptr,
-                      uint32_t slot_cap = 0, const K* src_slots = nullptr) {
+                      uint32_t slot_cap = 0, const K* src_slots = nullptr, uint32_t* list2 = nullptr, uint32_t* list2_count = nullptr) {
     constexpr int NW = local_waves(sizeof(K)), KPT = local_kpt(sizeof(K));
     constexpr size_t lds = local_lds_bytes(sizeof(K));
     const bool mapped = km.neg != 0 || km.pos != 0;
@@ -3095,6 +3361,30 @@ int launch_local_sort(K* keys, K* tmp, const uint32_t* bstart, const Plan* plan,
             else { if (mapped) RDST_COUNT(true, false); else RDST_COUNT(false, false); }
 #undef RDST_COUNT
             HIP_TRY(hipGetLastError());
+            if (g_tuning.expand && list2) {  // what the counting kernel listed (a value 16 times, a bucket over its tile): one block per CU
+                constexpr size_t elds = expand_lds_bytes();
+#define RDST_COUNT16(MAPPED, FROM16)                                                                                                 \
+    do {                                                                                                                             \
+        if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_count16_sort_kernel<MAPPED, FROM16>), elds)) return rc;    \
+        hipLaunchKernelGGL((local_count16_sort_kernel<MAPPED, FROM16>), dim3((uint32_t)cus), dim3(COUNT16_THREADS), elds, s, keys, tmp, \
+                           src16, bstart, plan, (uint32_t)km.neg, (uint32_t)km.pos, list, list_count, list2, list2_count, slot_count, slot_cap); \
+    } while (0)
+                if (src16) { if (mapped) RDST_COUNT16(true, true); else RDST_COUNT16(false, true); }
+                else { if (mapped) RDST_COUNT16(true, false); else RDST_COUNT16(false, false); }
+#undef RDST_COUNT16
+                HIP_TRY(hipGetLastError());
+#define RDST_EXPAND(MAPPED, FROM16)                                                                                                  \
+    do {                                                                                                                             \
+        if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_expand_sort_kernel<MAPPED, FROM16>), elds)) return rc;     \
+        hipLaunchKernelGGL((local_expand_sort_kernel<MAPPED, FROM16>), dim3((uint32_t)cus), dim3(EXPAND_THREADS), elds, s, keys, tmp, \
+                           src16, bstart, plan, err, (uint32_t)km.neg, (uint32_t)km.pos, list2, list2_count, slot_count, slot_cap); \
+    } while (0)
+                if (src16) { if (mapped) RDST_EXPAND(true, true); else RDST_EXPAND(false, true); }
+                else { if (mapped) RDST_EXPAND(true, false); else RDST_EXPAND(false, false); }
+#undef RDST_EXPAND
+                HIP_TRY(hipGetLastError());
+                return RDST_OK;  // (the list is spent: nothing is left for the ranked kernel)
+            }
         }
     }
     bool listed = counting;
@@ -3187,6 +3477,11 @@ int launch_pass(int cfg, K* keys, K* tmp, uint64_t n, int level, const Layout& L
     const bool mapped = km.neg != 0 || km.pos != 0;
     const bool narrow = n * sizeof(K) < (1ull << 32);
     if constexpr (sizeof(K) == 4) {
+        if (persist && out16 && cfg == 4 && L.status_bytes == 4 && narrow) {  // behind the atomic route: level L-1, whose pass feeds K4 on the hybrid route
+            constexpr int KPT = kpt_for(11, sizeof(K));
+            return mapped ? launch_pass_t<K, uint32_t, KPT, 12, 1, true, true, NoVal, true, true>(keys, tmp, n, level, L, ws, km, cus, s, nullptr, nullptr, out16)
+                          : launch_pass_t<K, uint32_t, KPT, 12, 1, false, true, NoVal, true, true>(keys, tmp, n, level, L, ws, km, cus, s, nullptr, nullptr, out16);
+        }
         if (persist && cfg == 4 && L.status_bytes == 4 && narrow) {  // the LSD fallback behind the atomic route
             constexpr int KPT = kpt_for(11, sizeof(K));
             return mapped ? launch_pass_t<K, uint32_t, KPT, 12, 1, true, true, NoVal, false, true>(keys, tmp, n, level, L, ws, km, cus, s)
@@ -3274,11 +3569,14 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     // enough that 65 536 tiles can hold it): K1h counts the buckets, route_kernel decides.  If it says LSD,
     // K1 runs as ever (the slice is then read twice for counting); if it says hybrid, K1 returns at once.
     const bool whole_sort = !HAS_V && level_lo == 0 && level_hi == (uint32_t)LEVELS && allow_skip && copy_back;
-    const bool try_atomic = whole_sort && atomic_eligible(n, sizeof(K), cfg);  // (its fallback is the LSD route: K1h is not tried then)
+    const bool try_atomic = whole_sort && atomic_eligible(n, sizeof(K), cfg);
     // 8-byte keys: the fallback's passes run as persistent blocks of shape 5 (eight skipped passes of one block per tile cost 0.5 ms per 10^9 keys)
     if (try_atomic && sizeof(K) == 8 && g_tuning.persist_fallback && g_tuning.pass_cfg < 0) cfg = 5;
-    const bool try_hybrid = whole_sort && !try_atomic && hybrid_eligible(n, sizeof(K));
-    const bool halves = try_hybrid && g_tuning.halves && g_tuning.count_sort && halves_possible<K>(cfg, n);
+    // Behind a failed atomic route (an area or a slot overflowed) the hybrid route is tried next — exact counts, any bucket
+    // the local sort takes — and the LSD route last.  One launch sequence serves all three: every kernel looks at the plan.
+    const bool halves_cfg = g_tuning.halves && g_tuning.count_sort && halves_possible<K>(cfg, n);
+    const bool try_hybrid = whole_sort && hybrid_eligible(n, sizeof(K)) && (!try_atomic || (g_tuning.chain_routes && (sizeof(K) == 8 || halves_cfg)));
+    const bool halves = try_hybrid && halves_cfg;
     const Layout L = make_layout(n, sizeof(K), LEVELS, cfg, HAS_V ? PAIR_WAVES * 64 * pair_kpt(sizeof(K), ValBytes<V>::value) : 0, halves, try_atomic);
     if (L.tiles >= (1ull << 31)) return fail(RDST_ERR_ARG, "len too large for one launch");
     rc = ensure_workspace(*D, L.total);
@@ -3296,7 +3594,7 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     // hybrid-eligible sorts clear the rows of the two levels that route uses now and leave the others to a conditional
     // kernel behind the route decision (1 B u32: 0.07 ms of clearing -> half)
     const size_t level_rows = (size_t)L.status_bytes * L.tiles * RADIX;  // one level, one copy
-    const bool split_clear = try_hybrid && LEVELS > 2;
+    const bool split_clear = try_hybrid && !try_atomic && LEVELS > 2;
     if (try_atomic) {
         HIP_TRY(hipMemsetAsync(ws, 0, L.off_status, s));  // the status rows are the LSD route's: cleared behind the route decision, if it fell that way
     } else if (split_clear) {
@@ -3377,16 +3675,12 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
             hipLaunchKernelGGL(msd_finish_kernel, dim3(1), dim3(1024), 0, s, fa);
             HIP_TRY(hipGetLastError());
             if ((rc = prof_mark(*D, s, RDST_STAGE_ROUTE))) return rc;
-            rc = launch_local_sort<K>(keys, tmp, reinterpret_cast<const uint32_t*>(ws + L.off_bstart), plan, D->err_dev, km,
-                                      reinterpret_cast<uint32_t*>(ws + L.off_fblist), reinterpret_cast<uint32_t*>(ws + L.off_err) + 3, slots16,
-                                      D->cus, s, cursor_b, slot_cap, slots);
-            if (rc) return rc;
-            if ((rc = prof_mark(*D, s, RDST_STAGE_LOCAL))) return rc;
-            // the LSD route's status rows, if the route fell that way
-            const uint64_t vecs = level_rows * LEVELS / 16;
-            hipLaunchKernelGGL(clear_unless_hybrid_kernel, dim3((uint32_t)D->cus * 4), dim3(256), 0, s, plan, reinterpret_cast<uint4*>(ws + L.off_status),
-                               vecs, reinterpret_cast<uint4*>(ws + L.off_status_near), vecs);
-            HIP_TRY(hipGetLastError());
+            if (!try_hybrid) {  // the LSD route's status rows, if the route fell that way
+                const uint64_t vecs = level_rows * LEVELS / 16;
+                hipLaunchKernelGGL(clear_unless_hybrid_kernel, dim3((uint32_t)D->cus * 4), dim3(256), 0, s, plan, reinterpret_cast<uint4*>(ws + L.off_status),
+                                   vecs, reinterpret_cast<uint4*>(ws + L.off_status_near), vecs, 0u);
+                HIP_TRY(hipGetLastError());
+            }
         }
     }
     if constexpr (!HAS_V && (sizeof(K) == 4 || sizeof(K) == 8)) {
@@ -3394,7 +3688,7 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
             uint32_t* overflow = reinterpret_cast<uint32_t*>(ws + L.off_err) + 2;
             uint32_t* h16 = reinterpret_cast<uint32_t*>(ws + L.off_h16);
             unsigned long long* hpos16 = reinterpret_cast<unsigned long long*>(ws + L.off_hpos16);
-            rc = launch_hist16<K>(keys, n, (uint32_t)blocks, km, h16, hpos16, inversion, overflow, plan, s);
+            rc = launch_hist16<K>(keys, n, (uint32_t)blocks, km, h16, hpos16, inversion, overflow, plan, s, !try_atomic);
             if (rc) return rc;
             if ((rc = prof_mark(*D, s, RDST_STAGE_HIST16))) return rc;
             RouteArgs ra{};
@@ -3409,13 +3703,18 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
             ra.plan = plan;
             ra.n = n;
             ra.levels = (uint32_t)LEVELS;
-            ra.cap = (uint32_t)local_tile(sizeof(K));
+            ra.cap = sizeof(K) == 4 && g_tuning.count_sort && g_tuning.expand ? EXPAND_MAX : (uint32_t)local_tile(sizeof(K));
             hipLaunchKernelGGL(route_kernel, dim3(1), dim3(1024), 0, s, ra);
             HIP_TRY(hipGetLastError());
             if (split_clear) {
                 const uint64_t vecs = level_rows * (LEVELS - 2) / 16;  // rows are multiples of 1 KiB
                 hipLaunchKernelGGL(clear_unless_hybrid_kernel, dim3((uint32_t)D->cus * 4), dim3(256), 0, s, plan,
-                                   reinterpret_cast<uint4*>(ws + L.off_status), vecs, reinterpret_cast<uint4*>(ws + L.off_status_near), vecs);
+                                   reinterpret_cast<uint4*>(ws + L.off_status), vecs, reinterpret_cast<uint4*>(ws + L.off_status_near), vecs, 0u);
+                HIP_TRY(hipGetLastError());
+            } else if (try_atomic) {  // nothing was cleared up front: every level's rows, unless the atomic route took the sort
+                const uint64_t vecs = level_rows * LEVELS / 16;
+                hipLaunchKernelGGL(clear_unless_hybrid_kernel, dim3((uint32_t)D->cus * 4), dim3(256), 0, s, plan,
+                                   reinterpret_cast<uint4*>(ws + L.off_status), vecs, reinterpret_cast<uint4*>(ws + L.off_status_near), vecs, 1u);
                 HIP_TRY(hipGetLastError());
             }
             if ((rc = prof_mark(*D, s, RDST_STAGE_ROUTE))) return rc;
@@ -3458,10 +3757,16 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
         if ((rc = prof_mark(*D, s, RDST_STAGE_PASS | (level << 8)))) return rc;
     }
     if constexpr (!HAS_V && (sizeof(K) == 4 || sizeof(K) == 8)) {
-        if (try_hybrid) {
+        if (try_hybrid || try_atomic) {
+            // one K4 for both routes: the atomic route's buckets lie in the slots, the hybrid route's at their final place
+            // (4-byte keys: as low halves, in the same region of the workspace either way)
+            const bool from16 = sizeof(K) == 4 && (try_atomic || halves);
             rc = launch_local_sort<K>(keys, tmp, reinterpret_cast<const uint32_t*>(ws + L.off_bstart), plan, D->err_dev, km,
                                       reinterpret_cast<uint32_t*>(ws + L.off_fblist), reinterpret_cast<uint32_t*>(ws + L.off_err) + 3,
-                                      halves ? reinterpret_cast<const uint16_t*>(ws + L.off_halves) : nullptr, D->cus, s);
+                                      from16 ? reinterpret_cast<const uint16_t*>(ws + L.off_halves) : nullptr, D->cus, s,
+                                      try_atomic ? reinterpret_cast<const uint32_t*>(ws + L.off_cursor_b) : nullptr, (uint32_t)local_tile(sizeof(K)),
+                                      try_atomic && sizeof(K) == 8 ? reinterpret_cast<const K*>(ws + L.off_halves) : nullptr,
+                                      reinterpret_cast<uint32_t*>(ws + L.off_fblist2), reinterpret_cast<uint32_t*>(ws + L.off_err) + 5);
             if (rc) return rc;
             if ((rc = prof_mark(*D, s, RDST_STAGE_LOCAL))) return rc;
         }
@@ -3722,6 +4027,9 @@ int rdst_hip_set_hybrid(int enabled, uint64_t min_len) {
     g_tuning.presample = enabled != 5;   // 5: no sample before K1h: every hybrid-eligible sort counts all its keys' prefixes first (tests)
     g_tuning.wide2 = enabled != 6;       // 6: 8-byte keys with the one-block-per-CU form of K4 (A/B, tests)
     g_tuning.atomic_route = enabled == 1 || enabled == 8;  // 1: the default (4- and 8-byte keys try the atomic route first); 2..7: the K1h hybrid route for every key width (7: with the default forms of K4)
+    g_tuning.chain_routes = enabled != 10; // 10: the default, but a failed atomic route falls straight to the LSD route (A/B, tests)
+    g_tuning.atomic_route = g_tuning.atomic_route || enabled == 10;
+    g_tuning.expand = enabled != 9;        // 9: the K1h hybrid route without the expanding K4 (buckets up to one tile; refused buckets to the ranked kernel) (A/B, tests)
     g_tuning.atomic_wide = enabled != 8;   // 8: the atomic route for 4-byte keys only, 8-byte keys on the K1h hybrid route (A/B, tests)
     g_tuning.hybrid_min_len = min_len ? min_len : (1ull << 28);
     return RDST_OK;

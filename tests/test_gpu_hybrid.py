@@ -14,27 +14,51 @@ pytestmark = pytest.mark.gpu
 TILE = {4: 16896, 8: 16384}  # K4 tile = largest bucket the hybrid route accepts
 
 
-@pytest.fixture(params=["count", "count_whole_keys", "ranked", "wide_one_block", "atomic", "atomic_4_only"])
+MODES = {"count": 7, "count_whole_keys": 3, "ranked": 2, "wide_one_block": 6, "atomic": True, "atomic_4_only": 8, "no_expand": 9,
+         "atomic_then_lsd": 10}
+
+
+@pytest.fixture(params=list(MODES))
 def hybrid(gpu, request):
-    """the forms of K4 for 4-byte keys: the counting sort by value fed with the 16-bit halves pass L-1 leaves in the
-    workspace ("count": the K1h hybrid route; 8-byte keys: two 512-thread blocks per CU, or — "wide_one_block" — one of 1024), the same fed with whole keys, the generic ranked passes (the fallback for buckets whose counters overflow), and "atomic": the library's default, in which
-    4- and 8-byte keys take the atomic route (MSD passes that claim space, no counting read; "atomic_4_only": 8-byte keys on
-    the hybrid one)"""
-    mode = {"count": 7, "count_whole_keys": 3, "ranked": 2, "wide_one_block": 6, "atomic": True, "atomic_4_only": 8}[request.param]
-    gpu.set_hybrid(mode, min_len=1)   # consider the route at every length (default: 2^28 and up)
+    """the routes and the forms of K4.  "count": the K1h hybrid route for every width — 4-byte keys: counting sort by value
+    fed with the 16-bit halves pass L-1 leaves in the workspace, refused buckets (a value 16 times, more than a tile) to the
+    expanding kernel; 8-byte keys: two 512-thread blocks per CU, or ("wide_one_block") one of 1024.  "count_whole_keys": the
+    same fed with whole keys.  "ranked": the generic ranked passes for every bucket.  "no_expand": without the expanding
+    kernel (buckets up to one tile only, refused buckets to the ranked kernel).  "atomic": the library's default — 4- and
+    8-byte keys try the atomic route (MSD passes that claim space, no counting read), then the hybrid one, then LSD
+    ("atomic_4_only": 8-byte keys start at the hybrid route; "atomic_then_lsd": no hybrid route behind a failed atomic one)."""
+    gpu.set_hybrid(MODES[request.param], min_len=1)   # consider the routes at every length (default: 2^28 and up)
     gpu._test_mode = request.param
     yield gpu
     gpu.set_hybrid(True, 0)
     gpu.set_tuning()
 
 
-def _fast_route(rdst, route, dtype, strict=True):
-    """the route a sort that CAN leave the LSD route must have taken: "hybrid" — except in the "atomic" modes of the fixture,
-    where 4-byte (and, in "atomic", 8-byte) keys take the atomic route; an input whose top byte is far from uniform overflows
-    that route's areas and falls to LSD (strict=False: both are fine)"""
+def _takes_atomic(rdst, dtype):
     mode, nb = getattr(rdst, "_test_mode", ""), np.dtype(dtype).itemsize
-    if (mode == "atomic" and nb in (4, 8)) or (mode == "atomic_4_only" and nb == 4):
-        return route == "atomic" or (not strict and route == "lsd")
+    return (mode in ("atomic", "atomic_then_lsd") and nb in (4, 8)) or (mode == "atomic_4_only" and nb == 4)
+
+
+def _bucket_cap(rdst, dtype):
+    """the largest bucket the hybrid route takes in this mode"""
+    mode, nb = getattr(rdst, "_test_mode", ""), np.dtype(dtype).itemsize
+    return 65535 if nb == 4 and mode not in ("ranked", "no_expand") else TILE[nb]
+
+
+def _skewed_route(rdst, dtype, fits):
+    """the route of an input the atomic route's areas cannot hold: the hybrid route if every bucket fits its bound"""
+    if _takes_atomic(rdst, dtype) and getattr(rdst, "_test_mode", "") == "atomic_then_lsd":
+        return "lsd"
+    return "hybrid" if fits else "lsd"
+
+
+def _fast_route(rdst, route, dtype, strict=True):
+    """the route a sort whose buckets all fit a tile must have taken: "hybrid" — except in the "atomic" modes of the fixture,
+    where the atomic route comes first; an input whose top bytes are far from uniform overflows that route's areas and falls
+    to the hybrid route (or, "atomic_then_lsd", the LSD one) (strict=False: these are fine too)"""
+    if _takes_atomic(rdst, dtype):
+        after = "lsd" if getattr(rdst, "_test_mode", "") == "atomic_then_lsd" else "hybrid"
+        return route == "atomic" or (not strict and route == after)
     return route == "hybrid"
 
 
@@ -94,25 +118,54 @@ def test_buckets_up_to_one_tile(hybrid, dtype):
     # demand a correct result here and check the route only when every bucket still fits
     got, route = _sort(hybrid, b)
     top = (mapped_key(b) >> np.array(w - 16, dtype=f"uint{w}")).astype(np.int64)
-    fits = np.bincount(top, minlength=65536).max() <= tile
+    fits = np.bincount(top, minlength=65536).max() <= _bucket_cap(hybrid, dtype)
     assert (route == "lsd") if not fits else _fast_route(hybrid, route, dtype, strict=False)
     assert same_bits(got, reference_sorted(b)), dtype
 
 
-def test_bucket_larger_than_a_tile_takes_the_lsd_route(hybrid):
+def test_bucket_larger_than_the_routes_bound(hybrid):
+    """8-byte keys, and 4-byte keys without the expanding K4: a bucket over one tile sends the sort down the LSD route;
+    4-byte keys by default: the hybrid route takes buckets of up to 65 535 keys (the expanding kernel sorts what is
+    over a tile), and one key more is the LSD route's."""
     for dtype in ("uint32", "float64"):
         tile = TILE[np.dtype(dtype).itemsize]
         a = _with_prefixes(40 * (tile + 2000), dtype, list(range(1000, 1040)), seed=5)
         got, route = _sort(hybrid, a)
-        assert route == "lsd"
+        assert route == _skewed_route(hybrid, dtype, _bucket_cap(hybrid, dtype) > tile), (dtype, route)
         assert same_bits(got, reference_sorted(a))
-    # exactly one key too many in one bucket
-    w = 32
-    low = random_bits(TILE[4] + 1, "uint32", seed=6) & np.uint32(0xFFFF)
-    a = np.concatenate([low | np.uint32(0xABCD0000), random_bits(100_000, "uint32", seed=7)])
-    got, route = _sort(hybrid, a)
-    assert route == "lsd"
-    assert same_bits(got, reference_sorted(a))
+    for extra in (0, 1):   # exactly the bound / one key too many in one bucket
+        cap = _bucket_cap(hybrid, "uint32")
+        low = random_bits(cap + extra, "uint32", seed=6) & np.uint32(0xFFFF)
+        a = np.concatenate([low | np.uint32(0xABCD0000), random_bits(100_000, "uint32", seed=7) & np.uint32(0x7FFFFFFF)])
+        got, route = _sort(hybrid, a)
+        assert route == _skewed_route(hybrid, "uint32", not extra), (extra, route)
+        assert same_bits(got, reference_sorted(a))
+
+
+def test_buckets_of_several_tiles_and_of_few_distinct_values(hybrid):
+    """what the expanding K4 is for (4-byte keys): buckets between one tile and 65 535 keys, and buckets whose low halves
+    repeat (a value 16 times overflows the counting kernel's 4-bit counters) — including buckets of ONE value, whose 64
+    equal keys per wave are added once."""
+    rng = np.random.default_rng(101)
+    for dtype in ("uint32", "int32", "float32"):
+        parts = []
+        for j, size in enumerate((20_000, 40_000, 65_535, 17_000, 16_897, 3, 700)):
+            low = rng.integers(0, 1 << 16, size=size, dtype=np.uint32)
+            if j % 3 == 1:
+                low &= np.uint32(0x00FF)          # 256 distinct values
+            if j % 3 == 2:
+                low[:] = 0x4242                   # one value
+            parts.append(low | np.uint32((0x0100 + 37 * j) << 16))
+        parts.append(rng.integers(0, 1 << 16, size=30_000, dtype=np.uint32) & np.uint32(0xF00F) | np.uint32(0x7001 << 16))
+        parts.append(random_bits(200_000, "uint32", seed=102))
+        a = np.concatenate(parts)
+        rng.shuffle(a)
+        a = a.view(dtype)
+        got, route = _sort(hybrid, a)
+        top = (mapped_key(a) >> np.uint32(16)).astype(np.int64)
+        fits = np.bincount(top, minlength=65536).max() <= _bucket_cap(hybrid, dtype)
+        assert route == _skewed_route(hybrid, dtype, fits), (dtype, route)   # (too skewed for the atomic route's areas in any mode)
+        assert same_bits(got, reference_sorted(a)), dtype
 
 
 def test_counter_overflow_in_k1h_is_detected(hybrid):

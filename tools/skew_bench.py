@@ -1,4 +1,5 @@
 """Development aid: device sort time on non-uniform inputs (1e9 u32 keys unless argv[1])."""
+import os
 import sys
 import torch
 sys.path.insert(0, ".")
@@ -43,4 +44,11 @@ for name, src in cases.items():
         times.append(e0.elapsed_time(e1))
     k = keys ^ (-(2**31))
     ok = bool((k[1:] >= k[:-1]).all()) and int(keys.sum()) == int(src.sum())
-    print(f"{name:36s}: {min(times):8.3f} ms  {n / min(times) / 1e6:7.1f} Gkeys/s  ok={ok}", flush=True)
+    print(f"{name:36s}: {min(times):8.3f} ms  {n / min(times) / 1e6:7.1f} Gkeys/s  ok={ok}  route={rdst_amd.last_route()}", flush=True)
+    if os.environ.get("RDST_STAGES"):
+        keys.copy_(src)
+        rdst_amd.set_profiling(True)
+        rdst_amd.sort_device_tensor(keys.view(torch.uint32), tmp, check=False)
+        p = rdst_amd.profile_run(-1, 4)
+        rdst_amd.set_profiling(False)
+        print("      " + "  ".join(f"{nm}{'' if lv is None else lv}={ms:.3f}" for nm, lv, ms in p["stages"] if ms >= 0.02), flush=True)
