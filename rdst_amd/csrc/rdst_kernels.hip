@@ -108,6 +108,7 @@ struct Plan {
     uint32_t local_sort;              // hybrid route and the slice is not already sorted: K4 runs
     uint32_t gross_skew;              // a sample of the keys already rules the hybrid route out (presample_kernel): K1h returns at once
     uint32_t top_skew;                // the sample's top bytes are far from uniform: the atomic route's areas would overflow, its passes return at once
+    uint32_t low_dups;                // (4-byte keys) the sample's low halves repeat: K4's first kernel (4-bit counters) would refuse most buckets, it hands them all on
     uint32_t sorted_known;            // K1h swept the whole slice and met no inversion: K1 need not read it again (K2 turns every pass off)
 };
 
@@ -423,7 +424,11 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const K* __restrict_
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t PRESAMPLE_KEYS = 8192;  // 65 536 spread-out keys cost 0.17 ms (a TLB miss each); 8 192 in one batch of loads: ~0.01 ms
 constexpr uint64_t PRESAMPLE_MIN_LEN = 1ull << 28;  // below it a full tile expects more hits than 8-bit counters and a small limit allow
-constexpr size_t presample_lds_bytes() { return H16_BINS + 16 + 4 * RADIX; }
+constexpr size_t presample_lds_bytes() { return 2 * H16_BINS + 16 + 4 * RADIX; }
+// low halves of the sample that were seen before: S - D (1 - exp(-S / D)) for S = 8 192 samples over D equally likely values:
+// ~490 on uniform keys (D = 65 536), 3 000 for D = 8 192, 5 000 for D ~ 3 500 — where a bucket of 15 000 keys holds each value
+// 4-5 times on average and one of them 16 times often enough that K4's first kernel refuses a good part of the buckets
+constexpr uint32_t PRESAMPLE_DUP_LIMIT = 5000;
 constexpr uint32_t PRESAMPLE_TOP_LIMIT = 2 * PRESAMPLE_KEYS / RADIX;  // twice a top byte's share of the sample (Poisson(32) >= 64: 2e-7)
 
 template <typename K, bool MAPPED>
@@ -431,12 +436,13 @@ __global__ __launch_bounds__(1024) void presample_kernel(const K* __restrict__ k
     constexpr int W = sizeof(K) * 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* s_c = reinterpret_cast<uint32_t*>(smem);               // 65 536 8-bit counters, four per word
-    uint32_t* s_skew = reinterpret_cast<uint32_t*>(smem + H16_BINS);   // [0] a prefix over the limit, [1] a top byte over its limit
+    uint32_t* s_skew = reinterpret_cast<uint32_t*>(smem + H16_BINS);   // [0] a prefix over the limit, [1] a top byte over its limit, [2] repeated low halves
     uint32_t* s_top = reinterpret_cast<uint32_t*>(smem + H16_BINS + 16); // [256] the sample's top bytes
+    uint32_t* s_low = reinterpret_cast<uint32_t*>(smem + H16_BINS + 16 + 4 * RADIX);  // 65 536 8-bit counters of the low halves (4-byte keys)
     const int tid = threadIdx.x;
-    for (int i = tid; i < H16_BINS / 4; i += 1024) s_c[i] = 0;
+    for (int i = tid; i < H16_BINS / 4; i += 1024) { s_c[i] = 0; s_low[i] = 0; }
     if (tid < RADIX) s_top[tid] = 0;
-    if (tid < 2) s_skew[tid] = 0;
+    if (tid < 4) s_skew[tid] = 0;
     __syncthreads();
     const uint64_t step = n / PRESAMPLE_KEYS;
     bool skew = false;
@@ -453,6 +459,11 @@ __global__ __launch_bounds__(1024) void presample_kernel(const K* __restrict__ k
             const uint32_t old = atomicAdd(&s_c[b >> 2], 1u << sh);
             skew |= ((old >> sh) & 0xFFu) + 1u >= limit;  // limit <= 64: the flag fires long before a counter could carry
             atomicAdd(&s_top[b >> 8], 1u);
+            if constexpr (sizeof(K) == 4) {
+                const uint32_t lo = (uint32_t)m & 0xFFFFu, lsh = (lo & 3u) * 8u;
+                const uint32_t seen = (atomicAdd(&s_low[lo >> 2], 1u << lsh) >> lsh) & 0xFFu;  // (a value 256 times carries: such a sample is far over the limit already)
+                if (seen) atomicAdd(&s_skew[2], 1u);
+            }
         }
     }
     if (skew) s_skew[0] = 1;
@@ -463,6 +474,7 @@ __global__ __launch_bounds__(1024) void presample_kernel(const K* __restrict__ k
     __syncthreads();
     if (tid == 0 && s_skew[0]) plan->gross_skew = 1;
     if (tid == 0 && s_skew[1]) plan->top_skew = 1;
+    if (tid == 0 && s_skew[2] >= PRESAMPLE_DUP_LIMIT) plan->low_dups = 1;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -632,10 +644,11 @@ struct RouteArgs {
     Plan* plan;
     uint64_t n;
     uint32_t levels, cap, allow_skip;
+    uint32_t mid_tile;  // 4-byte keys: buckets over this many keys go to the expanding K4 (~7 ns per 1 000 keys against ~1.5); 0: no such buckets
 };
 
 __global__ __launch_bounds__(1024) void route_kernel(RouteArgs a) {
-    __shared__ uint32_t s_wsum[16], s_wmax[16];
+    __shared__ uint32_t s_wsum[16], s_wmax[16], s_wmid[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (a.plan->route == ROUTE_ATOMIC) return;  // tried first, and it took the sort (msd_finish_kernel): nothing to decide
     uint32_t c[64];
@@ -651,6 +664,11 @@ __global__ __launch_bounds__(1024) void route_kernel(RouteArgs a) {
 #pragma unroll
     for (int k = 32; k < 64; ++k) { sum1 += c[k]; mx = c[k] > mx ? c[k] : mx; }
     const uint32_t mine = sum0 + sum1;
+    uint32_t mid = 0;  // keys in buckets over the middle kernel's tile (they cannot pass 2^32 in sum: n < 2^32)
+    if (a.mid_tile) {
+#pragma unroll
+        for (int k = 0; k < 64; ++k) mid += c[k] > a.mid_tile ? c[k] : 0u;
+    }
     uint32_t incl = mine, wmax = mx;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -658,16 +676,21 @@ __global__ __launch_bounds__(1024) void route_kernel(RouteArgs a) {
         if (lane >= o) incl += y;
         const uint32_t m = __shfl_xor(wmax, o);
         wmax = m > wmax ? m : wmax;
+        mid += __shfl_xor(mid, o);
     }
     if (lane == 63) s_wsum[wave] = incl;
-    if (lane == 0) s_wmax[wave] = wmax;
+    if (lane == 0) { s_wmax[wave] = wmax; s_wmid[wave] = mid; }
     __syncthreads();
     uint32_t excl = incl - mine, bmax = 0;
+    uint64_t bmid = 0;
     for (int w = 0; w < 16; ++w) {
         if (w < wave) excl += s_wsum[w];
         bmax = s_wmax[w] > bmax ? s_wmax[w] : bmax;
+        bmid += s_wmid[w];
     }
-    const bool hybrid = *a.overflow == 0 && bmax <= a.cap && a.plan->gross_skew == 0;  // (K1h returned at once then: its counts are all zero)
+    // the expanding kernel costs ~7 ns per 1 000 keys; the LSD route costs ~3.4 more than the hybrid one per 1 000 keys of the
+    // slice: with more than a third of the keys in such buckets the LSD route is the faster one
+    const bool hybrid = *a.overflow == 0 && bmax <= a.cap && a.plan->gross_skew == 0 && bmid * 3 <= a.n;  // (gross skew: K1h returned at once, its counts are all zero)
     if (tid == 0) {
         a.plan->route = hybrid ? ROUTE_HYBRID : ROUTE_LSD;
         a.plan->sorted_known = (a.plan->gross_skew == 0 && *a.inversion == 0 && a.allow_skip) ? 1u : 0u;
@@ -2153,7 +2176,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 8 : 6) void local_count_sort
         }
         return;
     }
-    if (cnt > (uint32_t)COUNT_TILE) {  // more than this kernel stages: the expanding kernel below takes it (any bucket below 65 536 keys)
+    if (cnt > (uint32_t)COUNT_TILE || plan->low_dups) {  // more than this kernel stages, or (the sample says) low halves its 4-bit counters cannot count: handed on
         if (tid == 0) list[atomicAdd(list_count, 1u)] = bucket;
         return;
     }
@@ -2400,22 +2423,36 @@ __global__ __launch_bounds__(COUNT16_THREADS) void local_count16_sort_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     auto word_of = [](uint32_t v) -> uint32_t { return (v >> 1) + (v >> 6); };
     const uint32_t total = *list_count;
-    for (uint32_t e = blockIdx.x; e < total; e += gridDim.x) {
+    // the keys of the next bucket are fetched while this one is sorted (one block per CU: nothing else hides the latency)
+    uint32_t nxt[KPT];
+    auto fetch = [&](uint32_t e) {
+        if (e >= total) return;
         const uint32_t bucket = list[e];
         const uint32_t start = bstart[bucket], cnt = slot_count ? slot_count[bucket] : bstart[bucket + 1] - start;
         const uint32_t soff = slot_count ? bucket * slot_cap : start;
-        if (cnt > (uint32_t)COUNT16_TILE) {
-            if (tid == 0) list2[atomicAdd(list2_count, 1u)] = bucket;
-            continue;
-        }
-        uint32_t kv[KPT];
+        if (cnt > (uint32_t)COUNT16_TILE || cnt == 0) return;
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
             const uint32_t idx = (uint32_t)tid + i * BLOCK;
             const uint32_t at = idx < cnt ? idx : cnt - 1;
-            if constexpr (FROM16) kv[i] = src16[soff + at];
-            else kv[i] = buf[start + at];
+            if constexpr (FROM16) nxt[i] = src16[soff + at];
+            else nxt[i] = buf[start + at];
         }
+    };
+    fetch(blockIdx.x);
+    for (uint32_t e = blockIdx.x; e < total; e += gridDim.x) {
+        const uint32_t bucket = list[e];
+        const uint32_t start = bstart[bucket], cnt = slot_count ? slot_count[bucket] : bstart[bucket + 1] - start;
+        if (cnt > (uint32_t)COUNT16_TILE) {
+            if (tid == 0) list2[atomicAdd(list2_count, 1u)] = bucket;
+            fetch(e + gridDim.x);
+            continue;
+        }
+        uint32_t kv[KPT];
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) kv[i] = nxt[i];
+        // (in place — not FROM16, the hybrid route fed with whole keys — the next bucket is another range of buf: no hazard)
+        fetch(e + gridDim.x);
         {
             uint4* t4 = reinterpret_cast<uint4*>(tab);
             const uint4 z = {0, 0, 0, 0};
@@ -3098,6 +3135,7 @@ struct Layout {
     size_t off_err, off_tickets, off_plan, off_hpos, off_hpair, off_h16, off_hpos16, off_status, off_status_near, zero_bytes, off_hist, off_base,
         off_cbase, off_chains, off_bstart, off_fblist, off_fblist2, off_halves, off_cursor_a, off_cursor_b, off_msd_a, total;
     uint32_t msd_cap_a, msd_slices;  // ROUTE_ATOMIC: keys an area of pass A holds; areas per top digit
+    uint32_t slot_cap;               // and keys a bucket's slot (pass B's destination) holds
 };
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -3141,7 +3179,14 @@ Layout make_layout(uint64_t n, uint32_t elem_bytes, uint32_t levels, int cfg, ui
     L.off_halves = o;                                                       // hybrid route, 4-byte keys: low halves between pass L-1 and K4
     if (want_halves && !want_msd) o += align_up(sizeof(uint16_t) * n, 256);
     // ROUTE_ATOMIC: 65 536 slots of one K4 tile each — low halves of 4-byte keys, whole 8-byte keys
-    if (want_msd) o += align_up((elem_bytes == 4 ? sizeof(uint16_t) : (size_t)elem_bytes) * H16_BINS * local_tile(elem_bytes), 256);
+    L.slot_cap = 0;
+    if (want_msd) {  // a slot holds a uniform bucket with ten sigma to spare (8 sigma fit a K4 tile: atomic_eligible), at most one K4 tile
+        const double mean = (double)n / H16_BINS;
+        const uint64_t want = ((uint64_t)(mean + 10.0 * __builtin_sqrt(mean)) + 64 + 63) / 64 * 64;
+        L.slot_cap = (uint32_t)(want < (uint64_t)local_tile(elem_bytes) ? want : (uint64_t)local_tile(elem_bytes));
+        o += align_up((elem_bytes == 4 ? sizeof(uint16_t) : (size_t)elem_bytes) * H16_BINS * L.slot_cap, 256);
+        if (o - L.off_halves < sizeof(uint16_t) * n) o = L.off_halves + align_up(sizeof(uint16_t) * n, 256);  // (the hybrid route's halves use the same space)
+    }
     L.off_msd_a = o;
     L.msd_cap_a = 0;
     L.msd_slices = 1;
@@ -3636,7 +3681,7 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
             constexpr int KPT = msd_kpt(sizeof(K)), NW = MSD_WAVES, TILE = NW * 64 * KPT, W = (int)sizeof(K) * 8;
             constexpr bool HALF = sizeof(K) == 4;  // 4-byte keys leave pass B as their low halves
             constexpr size_t mlds = (size_t)NW * 1024 + 1024 + 64 + sizeof(K) * TILE;
-            const uint32_t slot_cap = (uint32_t)local_tile(sizeof(K));
+            const uint32_t slot_cap = L.slot_cap;
             uint32_t* overflow = reinterpret_cast<uint32_t*>(ws + L.off_err) + 4;
             uint32_t* cursor_a = reinterpret_cast<uint32_t*>(ws + L.off_cursor_a);
             uint32_t* cursor_b = reinterpret_cast<uint32_t*>(ws + L.off_cursor_b);
@@ -3704,6 +3749,7 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
             ra.n = n;
             ra.levels = (uint32_t)LEVELS;
             ra.cap = sizeof(K) == 4 && g_tuning.count_sort && g_tuning.expand ? EXPAND_MAX : (uint32_t)local_tile(sizeof(K));
+            ra.mid_tile = ra.cap == EXPAND_MAX && n >= (1u << 24) ? (uint32_t)COUNT16_TILE : 0u;  // (short slices: the test is not worth a wrong guess either way)
             hipLaunchKernelGGL(route_kernel, dim3(1), dim3(1024), 0, s, ra);
             HIP_TRY(hipGetLastError());
             if (split_clear) {
@@ -3764,7 +3810,7 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
             rc = launch_local_sort<K>(keys, tmp, reinterpret_cast<const uint32_t*>(ws + L.off_bstart), plan, D->err_dev, km,
                                       reinterpret_cast<uint32_t*>(ws + L.off_fblist), reinterpret_cast<uint32_t*>(ws + L.off_err) + 3,
                                       from16 ? reinterpret_cast<const uint16_t*>(ws + L.off_halves) : nullptr, D->cus, s,
-                                      try_atomic ? reinterpret_cast<const uint32_t*>(ws + L.off_cursor_b) : nullptr, (uint32_t)local_tile(sizeof(K)),
+                                      try_atomic ? reinterpret_cast<const uint32_t*>(ws + L.off_cursor_b) : nullptr, L.slot_cap,
                                       try_atomic && sizeof(K) == 8 ? reinterpret_cast<const K*>(ws + L.off_halves) : nullptr,
                                       reinterpret_cast<uint32_t*>(ws + L.off_fblist2), reinterpret_cast<uint32_t*>(ws + L.off_err) + 5);
             if (rc) return rc;
