@@ -131,10 +131,13 @@ def kernel_table(rdst_amd, runs, n, kb, levels):
             continue
         moving = max([ms for nm, _lv, ms in prof["stages"] if nm in ("pass", "msd_pass_a", "msd_pass_b", "local_sort")] or [0.0])
         for name, _level, ms in prof["stages"]:
-            if name in ("pass", "histogram") and ms < 0.25 * moving and ms < 0.1:
+            if name in ("pass", "histogram", "histogram16", "msd_pass_a", "msd_pass_b", "local_sort") and ms < 0.25 * moving and ms < 0.1:
                 name += "_skipped"
             acc.setdefault(name, []).append(ms)
-    alg = {"pass": 2 * kb * n, "msd_pass_a": 2 * kb * n, "msd_pass_b": 2 * kb * n, "local_sort": 2 * kb * n, "histogram": kb * n, "histogram16": kb * n}
+    # (4-byte keys travel from the last scatter pass to K4 as their low 16-bit halves: 4 + 2 and 2 + 4 bytes per key)
+    half = kb == 4
+    alg = {"pass": 2 * kb * n, "msd_pass_a": 2 * kb * n, "msd_pass_b": (6 if half else 2 * kb) * n,
+           "local_sort": (6 if half else 2 * kb) * n, "histogram": kb * n, "histogram16": kb * n}
     out = {}
     for name, v in acc.items():
         avg = sum(v) / len(v)
@@ -143,6 +146,32 @@ def kernel_table(rdst_amd, runs, n, kb, levels):
             gbps = alg[name] / (avg * 1e-3) / 1e9
             e.update({"algorithmic_bytes_per_launch": alg[name], "GBps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 4)})
         out[name] = e
+    return out
+
+
+def route_bytes_per_key(route, kb, levels):
+    """HBM bytes the route moves per key when everything goes to plan: atomic: pass A (read + write), pass B
+    (read + write; 4-byte keys leave it as 16-bit halves), K4 (read + write); hybrid: K1h's read on top, both passes whole
+    keys but for the last one's halves; LSD: K1's read and a read + write per level."""
+    if route == "atomic":
+        return {4: 4 + 4 + 4 + 2 + 2 + 4, 8: 6 * 8}.get(kb)
+    if route == "hybrid":
+        return {4: 4 + 4 + 4 + 4 + 2 + 2 + 4, 8: 7 * 8}.get(kb)
+    return kb * (2 * levels + 1)
+
+
+def sort_level_fields(route, kb, levels, keys_per_gpu_per_s):
+    """the sort as a whole against HBM: by SURVEY.md §8(d)'s convention (the bytes an LSD sort of this key width moves — the
+    figure round 1's target was set in; a route that moves fewer bytes can pass 1.0 here) and by the bytes the route
+    that ran really moves"""
+    b_lsd, b_route = kb * (2 * levels + 1), route_bytes_per_key(route, kb, levels)
+    out = {"sort_algorithmic_bytes_per_key": b_lsd,
+           "sort_algorithmic_GBps": round(keys_per_gpu_per_s * b_lsd / 1e9, 1),
+           "sort_roofline_frac_per_gpu": round(keys_per_gpu_per_s * b_lsd / 1e9 / HBM_PEAK_GBPS, 4),
+           "sort_roofline_note": "LSD-equivalent bytes (SURVEY §8(d): k(2L+1) per key) / time / 8 TB/s; see route_* for the bytes this route moves"}
+    if b_route:
+        out.update({"route_bytes_per_key": b_route, "route_GBps": round(keys_per_gpu_per_s * b_route / 1e9, 1),
+                    "route_hbm_frac_per_gpu": round(keys_per_gpu_per_s * b_route / 1e9 / HBM_PEAK_GBPS, 4)})
     return out
 
 
@@ -259,7 +288,7 @@ def main():
     ms_per_step = elapsed / K * 1e3
     roof = None
     # the dominant kernel: the scatter pass — K3 (onesweep_kernel) on the LSD and hybrid routes, msd_scatter_kernel on the atomic one
-    dom = [k for k in ("msd_pass_a", "msd_pass_b", "pass") if k in kernels and "GBps" in kernels[k]]
+    dom = [k for k in ("msd_pass_a", "pass") if k in kernels and "GBps" in kernels[k]][:1]
     if dom:
         launches = sum(kernels[k]["launches"] for k in dom)
         avg_ms = sum(kernels[k]["avg_ms"] * kernels[k]["launches"] for k in dom) / launches
@@ -270,11 +299,14 @@ def main():
         if os.path.exists(tp) and not distributed and n == KEYS_PER_GPU and name == "u32":
             try:
                 tj = json.load(open(tp))
-                traffic = tj.get("scatter_pass_hbm_bytes_per_launch", tj.get("onesweep_pass_hbm_bytes_per_launch"))
+                if "msd_pass_a" in dom:
+                    traffic = tj["kernels"]["msd_scatter_kernel.pass_a"]["hbm_bytes_per_launch"]
+                else:
+                    traffic = tj.get("onesweep_pass_hbm_bytes_per_launch", tj.get("scatter_pass_hbm_bytes_per_launch"))
                 traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; not measured in this run)"
             except Exception:  # noqa: BLE001
                 traffic = None
-        roof = {"bound": "hbm", "kernel": ("msd_scatter_kernel (one MSD scatter pass; mean of passes A and B)" if "msd_pass_a" in dom
+        roof = {"bound": "hbm", "kernel": ("msd_scatter_kernel, pass A (whole keys in, whole keys out: the launch that moves the most bytes)" if "msd_pass_a" in dom
                                            else "onesweep_kernel (K3, one scatter pass)"),
                 "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": traffic,
                 "traffic_source": traffic_src, "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": round(avg_ms, 4),
@@ -292,9 +324,7 @@ def main():
                                    + (", sharded: MSD top byte + RCCL all-to-all + local sort" if distributed else ""),
                        "keys_per_gpu": n, "total_keys": n * world, "seed": seed, "route": route,
                        "parallelism": f"shard{world}" if distributed else "single"},
-            "sort_algorithmic_bytes_per_key": B_key,
-            "sort_algorithmic_GBps": round(total_keys * B_key / elapsed / 1e9 / world, 1),
-            "sort_roofline_frac_per_gpu": round(total_keys * B_key / elapsed / 1e9 / world / HBM_PEAK_GBPS, 4),
+            **sort_level_fields(route, kb, levels, total_keys / elapsed / world),
             "roofline": roof,
             "kernels": kernels,
         }
@@ -345,13 +375,10 @@ def main():
                 it2 = torch.int32 if kb2 == 4 else torch.int64
                 assert is_sorted(torch, mapped_signed(torch, out2.view(it2), other)), f"{other}: output not sorted"
                 assert int(out2.view(it2).sum()) == int(src2.sum()), f"{other}: checksum differs"
-                B2 = kb2 * (2 * lv2 + 1)
                 med = statistics.median(ps2)
                 configs[other] = {"keys": n, "steps": k2, "route": rdst_amd.last_route(), "ms_per_step": round(el2 / k2 * 1e3, 4),
                                   "median_ms_per_step": round(med, 4), "Gkeys_per_s": round(n * k2 / el2 / 1e9, 3),
-                                  "sort_algorithmic_bytes_per_key": B2,
-                                  "roofline": {"bound": "hbm", "achieved": round(n * k2 * B2 / el2 / 1e9, 1), "peak": HBM_PEAK_GBPS,
-                                               "unit": "GB/s", "frac": round(n * k2 * B2 / el2 / 1e9 / HBM_PEAK_GBPS, 4)},
+                                  **sort_level_fields(rdst_amd.last_route(), kb2, lv2, n * k2 / el2),
                                   "kernels": kernel_table(rdst_amd, runs2, n, kb2, lv2)}
                 rdst_amd.set_profiling(False)
                 del src2, out2, bufs2, tmp2
