@@ -108,6 +108,7 @@ struct Plan {
     uint32_t local_sort;              // hybrid route and the slice is not already sorted: K4 runs
     uint32_t gross_skew;              // a sample of the keys already rules the hybrid route out (presample_kernel): K1h returns at once
     uint32_t top_skew;                // the sample's top bytes are far from uniform: the atomic route's areas would overflow, its passes return at once
+    uint32_t giants, giant_count_items, giant_expand_items;  // hybrid route, 4-byte keys: buckets of 65 536 keys and more and the work items of their kernels (route_kernel)
     uint32_t low_dups;                // (4-byte keys) the sample's low halves repeat: K4's first kernel (4-bit counters) would refuse most buckets, it hands them all on
     uint32_t sorted_known;            // K1h swept the whole slice and met no inversion: K1 need not read it again (K2 turns every pass off)
 };
@@ -496,14 +497,18 @@ constexpr int H16_WORDS = H16_BINS / 2;
 #define RDST_H16_BATCH 4
 #endif
 
-template <typename K, int VEC, bool MAPPED>
+// GIANT (4-byte keys): buckets of any size are counted exactly.  A counter is then 15 bits and a guard bit: the add that sets
+// the guard (it sees 32 767 or less before, 32 768 or more after) owns the wrap — it takes the 32 768 back out of the
+// counter and adds them to the global tables at once.  The guard keeps a wrap from carrying into the neighbouring counter
+// (for that, 32 768 more adds would have to hit the counter between the owner's two instructions).
+template <typename K, int VEC, bool MAPPED, bool GIANT = false>
 __global__ __launch_bounds__(HIST_THREADS) void hist16_kernel(const K* __restrict__ keys, uint64_t n, K neg, K pos,
                                                               uint32_t* __restrict__ h16 /* [65536] bucket counts */,
-                                                              unsigned long long* __restrict__ hpos16 /* [CHAINS][256]: digit L-2 per position range */,
+                                                              unsigned long long* __restrict__ hpos16 /* [2][CHAINS][256]: digits L-2 and L-1 per position range */,
                                                               uint32_t* __restrict__ inversion, uint32_t* __restrict__ overflow,
                                                               const Plan* __restrict__ plan) {
     constexpr int W = sizeof(K) * 8;
-    if (plan->gross_skew) return;  // the sample ruled the hybrid route out: K1 will count (and look for inversions) instead
+    if (plan->gross_skew && !GIANT) return;  // the sample ruled the hybrid route out: K1 will count (and look for inversions) instead
     if (plan->route == ROUTE_ATOMIC) return;  // the atomic route was tried first and took the sort
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* s_h = reinterpret_cast<uint32_t*>(smem);
@@ -526,9 +531,22 @@ __global__ __launch_bounds__(HIST_THREADS) void hist16_kernel(const K* __restric
         inv |= before > m;
         const uint32_t b = (uint32_t)(m >> (W - 16));
         uint32_t* w = &s_h[b >> 1];
-        const uint32_t inc = 1u << ((b & 1u) * 16);
+        const uint32_t sh = (b & 1u) * 16;
+        const uint32_t inc = 1u << sh;
         // sorted or low-entropy input puts a whole wave on one counter (64 serialised atomics): one lane adds then
-        if (careful && __all((int)(b == (uint32_t)__builtin_amdgcn_readfirstlane((int)b))) != 0) {
+        const bool uniform = careful && __all((int)(b == (uint32_t)__builtin_amdgcn_readfirstlane((int)b))) != 0;
+        if constexpr (GIANT) {
+            const uint32_t k = uniform ? 64u : 1u;
+            if (!uniform || (tid & 63) == 0) {
+                const uint32_t before_add = (atomicAdd(w, k << sh) >> sh) & 0xFFFFu;
+                if (before_add < 0x8000u && before_add + k >= 0x8000u) {  // this add set the guard bit: the wrap is mine
+                    atomicSub(w, 0x8000u << sh);
+                    atomicAdd(&h16[b], 0x8000u);
+                    atomicAdd(&hpos16[(size_t)hist_range_of(blockIdx.x, gridDim.x) * RADIX + (b & 255u)], 0x8000ull);
+                    atomicAdd(&hpos16[(size_t)(CHAINS + hist_range_of(blockIdx.x, gridDim.x)) * RADIX + (b >> 8)], 0x8000ull);
+                }
+            }
+        } else if (uniform) {
             if ((tid & 63) == 0) atomicAdd(w, inc * 64u);
         } else {
             atomicAdd(w, inc);
@@ -619,9 +637,17 @@ __global__ __launch_bounds__(HIST_THREADS) void hist16_kernel(const K* __restric
         }
         const uint32_t range = hist_range_of(blockIdx.x, gridDim.x);
         if (c) atomicAdd(&hpos16[(size_t)range * RADIX + d], (unsigned long long)c);
+        // and digit L-1 (the high byte): if level L-2 turns out trivial, pass L-1 is the first to run and splits its source
+        // by position.  (Same-bank reads, 64 per thread, once per block.)
+        uint32_t ch = 0;
+        for (int lo2 = q * 32; lo2 < q * 32 + 32; ++lo2) {
+            const uint32_t v = s_h[d * 128 + lo2];
+            ch += (v >> 16) + (v & 0xFFFFu);
+        }
+        if (ch) atomicAdd(&hpos16[(size_t)(CHAINS + range) * RADIX + d], (unsigned long long)ch);
     }
     __syncthreads();
-    if (tid == 0) {
+    if (tid == 0 && !GIANT) {  // (GIANT: wraps were moved to the global tables as they happened, nothing is lost)
         const uint64_t counted = p_end > p_begin ? p_end - p_begin : 0;
         if (s_sum != counted) atomicOr(overflow, 1u);
     }
@@ -635,7 +661,7 @@ __global__ __launch_bounds__(HIST_THREADS) void hist16_kernel(const K* __restric
 // ------------------------------------------------------------------------------------------
 struct RouteArgs {
     const uint32_t* h16;              // [65536]
-    const unsigned long long* hpos16; // [CHAINS][256]
+    const unsigned long long* hpos16; // [2][CHAINS][256]
     const uint32_t* overflow;
     const uint32_t* inversion;        // K1h's "some key is smaller than its predecessor"
     uint32_t* bstart;                 // [65537] out
@@ -645,10 +671,20 @@ struct RouteArgs {
     uint64_t n;
     uint32_t levels, cap, allow_skip;
     uint32_t mid_tile;  // 4-byte keys: buckets over this many keys go to the expanding K4 (~7 ns per 1 000 keys against ~1.5); 0: no such buckets
+    // 4-byte keys: buckets of 65 536 keys and more ("giants") are sorted by the giant kernels of K4 — at most giant_max of
+    // them (a 256-KiB table each); 0: such a bucket sends the sort down the LSD route
+    uint32_t giant_max;
+    uint32_t* glist;        // [giant_max] out: the giants, in bucket order
+    uint32_t* gcount_item;  // [giant_max + 1] out: first work item of each in the counting kernel (two per chunk of GIANT_CHUNK keys)
+    uint32_t* gexp_item;    // [giant_max + 1] out: first work item of each in the expanding kernel (one per GIANT_OUT positions)
 };
+constexpr uint32_t GIANT_MIN = 65536;      // keys: below it the 16-bit counters of the LDS kernels do
+constexpr uint32_t GIANT_CHUNK = 1u << 19; // keys a block of the giant counting kernel streams per item (and value half)
+constexpr uint32_t GIANT_OUT = 1u << 14;   // positions a block of the giant expanding kernel writes per item
+constexpr uint32_t GIANT_TABLE = H16_BINS + 16;  // words per giant: 65 536 counts / prefixes, then the total
 
 __global__ __launch_bounds__(1024) void route_kernel(RouteArgs a) {
-    __shared__ uint32_t s_wsum[16], s_wmax[16], s_wmid[16];
+    __shared__ uint32_t s_wsum[16], s_wmax[16], s_wmid[16], s_wg[16], s_wci[16], s_wei[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (a.plan->route == ROUTE_ATOMIC) return;  // tried first, and it took the sort (msd_finish_kernel): nothing to decide
     uint32_t c[64];
@@ -658,44 +694,74 @@ __global__ __launch_bounds__(1024) void route_kernel(RouteArgs a) {
         const uint4 v = src[k];
         c[4 * k] = v.x; c[4 * k + 1] = v.y; c[4 * k + 2] = v.z; c[4 * k + 3] = v.w;
     }
-    uint32_t sum0 = 0, sum1 = 0, mx = 0;
+    const bool giants_ok = a.giant_max != 0;
+    uint32_t sum0 = 0, sum1 = 0, mx = 0;  // mx: the largest bucket the LDS kernels of K4 would have to take
+    uint32_t ng = 0, nci = 0, nei = 0;    // my giants, their counting and expanding work items
 #pragma unroll
-    for (int k = 0; k < 32; ++k) { sum0 += c[k]; mx = c[k] > mx ? c[k] : mx; }
-#pragma unroll
-    for (int k = 32; k < 64; ++k) { sum1 += c[k]; mx = c[k] > mx ? c[k] : mx; }
+    for (int k = 0; k < 64; ++k) {
+        if (k < 32) sum0 += c[k];
+        else sum1 += c[k];
+        if (giants_ok && c[k] >= GIANT_MIN) {
+            ++ng;
+            nci += 2u * ((c[k] + GIANT_CHUNK - 1) / GIANT_CHUNK);
+            nei += (c[k] + GIANT_OUT - 1) / GIANT_OUT;
+        } else {
+            mx = c[k] > mx ? c[k] : mx;
+        }
+    }
     const uint32_t mine = sum0 + sum1;
     uint32_t mid = 0;  // keys in buckets over the middle kernel's tile (they cannot pass 2^32 in sum: n < 2^32)
     if (a.mid_tile) {
 #pragma unroll
-        for (int k = 0; k < 64; ++k) mid += c[k] > a.mid_tile ? c[k] : 0u;
+        for (int k = 0; k < 64; ++k) mid += (c[k] > a.mid_tile && !(giants_ok && c[k] >= GIANT_MIN)) ? c[k] : 0u;
     }
-    uint32_t incl = mine, wmax = mx;
+    uint32_t incl = mine, wmax = mx, ig = ng, ici = nci, iei = nei;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t y = __shfl_up(incl, o);
-        if (lane >= o) incl += y;
+        const uint32_t y = __shfl_up(incl, o), yg = __shfl_up(ig, o), yc = __shfl_up(ici, o), ye = __shfl_up(iei, o);
+        if (lane >= o) { incl += y; ig += yg; ici += yc; iei += ye; }
         const uint32_t m = __shfl_xor(wmax, o);
         wmax = m > wmax ? m : wmax;
         mid += __shfl_xor(mid, o);
     }
-    if (lane == 63) s_wsum[wave] = incl;
+    if (lane == 63) { s_wsum[wave] = incl; s_wg[wave] = ig; s_wci[wave] = ici; s_wei[wave] = iei; }
     if (lane == 0) { s_wmax[wave] = wmax; s_wmid[wave] = mid; }
     __syncthreads();
-    uint32_t excl = incl - mine, bmax = 0;
+    uint32_t excl = incl - mine, bmax = 0, eg = ig - ng, eci = ici - nci, eei = iei - nei, tg = 0, tci = 0, tei = 0;
     uint64_t bmid = 0;
     for (int w = 0; w < 16; ++w) {
-        if (w < wave) excl += s_wsum[w];
+        if (w < wave) { excl += s_wsum[w]; eg += s_wg[w]; eci += s_wci[w]; eei += s_wei[w]; }
         bmax = s_wmax[w] > bmax ? s_wmax[w] : bmax;
         bmid += s_wmid[w];
+        tg += s_wg[w]; tci += s_wci[w]; tei += s_wei[w];
     }
     // the expanding kernel costs ~7 ns per 1 000 keys; the LSD route costs ~3.4 more than the hybrid one per 1 000 keys of the
     // slice: with more than a third of the keys in such buckets the LSD route is the faster one
-    const bool hybrid = *a.overflow == 0 && bmax <= a.cap && a.plan->gross_skew == 0 && bmid * 3 <= a.n;  // (gross skew: K1h returned at once, its counts are all zero)
+    const bool hybrid = *a.overflow == 0 && bmax <= a.cap && (giants_ok ? tg <= a.giant_max : a.plan->gross_skew == 0) &&
+                        bmid * 3 <= a.n;  // (gross skew without the giant kernels: K1h returned at once, its counts are all zero)
     if (tid == 0) {
         a.plan->route = hybrid ? ROUTE_HYBRID : ROUTE_LSD;
-        a.plan->sorted_known = (a.plan->gross_skew == 0 && *a.inversion == 0 && a.allow_skip) ? 1u : 0u;
+        a.plan->sorted_known = ((giants_ok || a.plan->gross_skew == 0) && *a.inversion == 0 && a.allow_skip) ? 1u : 0u;
+        a.plan->giants = hybrid ? tg : 0u;
+        a.plan->giant_count_items = hybrid ? tci : 0u;
+        a.plan->giant_expand_items = hybrid ? tei : 0u;
     }
     if (!hybrid) return;
+    if (giants_ok && tg) {
+        const uint32_t bucket0 = (uint32_t)tid * 64u;
+#pragma unroll
+        for (int k = 0; k < 64; ++k) {
+            if (c[k] >= GIANT_MIN) {
+                a.glist[eg] = bucket0 + (uint32_t)k;
+                a.gcount_item[eg] = eci;
+                a.gexp_item[eg] = eei;
+                ++eg;
+                eci += 2u * ((c[k] + GIANT_CHUNK - 1) / GIANT_CHUNK);
+                eei += (c[k] + GIANT_OUT - 1) / GIANT_OUT;
+            }
+        }
+        if (tid == 1023) { a.gcount_item[tg] = tci; a.gexp_item[tg] = tei; }
+    }
     uint32_t run = excl;
     uint4* dst = reinterpret_cast<uint4*>(a.bstart) + (size_t)tid * 16;
 #pragma unroll
@@ -712,13 +778,12 @@ __global__ __launch_bounds__(1024) void route_kernel(RouteArgs a) {
     // level L-1, pair counts: (digit dh, group of the level L-2 digit)
     a.hpair[((size_t)top * CHAINS + 2 * q) * RADIX + dh] = sum0;
     a.hpair[((size_t)top * CHAINS + 2 * q + 1) * RADIX + dh] = sum1;
-    // level L-1 totals go to range 0 (the pass runs second: its chains come from the pair counts)
-    uint32_t tot = mine;
-    tot += __shfl_xor(tot, 1);
-    tot += __shfl_xor(tot, 2);
-    if (q == 0) a.hpos[((size_t)top * CHAINS) * RADIX + dh] = tot;
-    // level L-2, per position range: as K1h counted them
-    for (int j = tid; j < CHAINS * RADIX; j += 1024) a.hpos[(size_t)(top - 1) * CHAINS * RADIX + j] = a.hpos16[j];
+    // levels L-2 and L-1, per position range: as K1h counted them (pass L-1 normally runs second and takes its chains from the
+    // pair counts; with a trivial level L-2 it runs first and splits by position)
+    for (int j = tid; j < CHAINS * RADIX; j += 1024) {
+        a.hpos[(size_t)(top - 1) * CHAINS * RADIX + j] = a.hpos16[j];
+        a.hpos[(size_t)top * CHAINS * RADIX + j] = a.hpos16[CHAINS * RADIX + j];
+    }
 }
 
 // ROUTE_ATOMIC, after its two scatter passes: did every claim fit?  Then the 65 536 claim counters are the bucket lengths:
@@ -2176,6 +2241,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 8 : 6) void local_count_sort
         }
         return;
     }
+    if (cnt >= GIANT_MIN && plan->giants) return;  // the giant kernels' (route_kernel listed it)
     if (cnt > (uint32_t)COUNT_TILE || plan->low_dups) {  // more than this kernel stages, or (the sample says) low halves its 4-bit counters cannot count: handed on
         if (tid == 0) list[atomicAdd(list_count, 1u)] = bucket;
         return;
@@ -2197,7 +2263,23 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 8 : 6) void local_count_sort
 #pragma unroll
     for (int k = 0; k < WPT; ++k) cnt4[k * BLOCK + tid] = 0;
     if (tid == 0) s_wsum[16] = 0;
-    __syncthreads();
+    // a bucket of ONE value (bimodal input: every key of the shifted half) needs no sorting, and would overflow the counters
+    bool differ = false;
+    {
+        const uint32_t first = FROM16 ? (uint32_t)src16[soff] : buf[start];
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i) differ |= kv[i] != first;  // (slots past cnt repeat the last key)
+    }
+    if (!__syncthreads_or((int)differ)) {
+        const uint32_t m = FROM16 ? ((bucket << 16) | kv[0]) : kv[0];
+        const uint32_t out = FROM16 && MAPPED ? unmap_key<uint32_t>(m, neg, pos) : m;
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i) {
+            const uint32_t idx = (uint32_t)tid + i * BLOCK;
+            if (idx < cnt && (FROM16 || slot_count)) buf[start + idx] = out;  // (whole keys in place are where they belong already)
+        }
+        return;
+    }
     __builtin_amdgcn_s_setprio(0);
     auto word_of = [](uint32_t v) -> uint32_t { return ((v >> 3) & (uint32_t)(WPT - 1)) * BLOCK + (v >> LOG_VPT); };
     bool over = false;
@@ -2453,6 +2535,27 @@ __global__ __launch_bounds__(COUNT16_THREADS) void local_count16_sort_kernel(
         for (int i = 0; i < KPT; ++i) kv[i] = nxt[i];
         // (in place — not FROM16, the hybrid route fed with whole keys — the next bucket is another range of buf: no hazard)
         fetch(e + gridDim.x);
+        {   // a bucket of one value: written at once (its 64-key waves would each add once, but the table work is the cost)
+            bool differ = false;
+            const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)kv[0]);  // every wave's lane 0 holds a key of the bucket's first 1 024
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) differ |= kv[i] != first;
+            if (tid == 0) s_wsum[16] = kv[0];
+            const int any = __syncthreads_or((int)differ);
+            const bool one = !any && first == s_wsum[16];  // each wave is constant: and they agree (every wave with a key compares with wave 0's)
+            if (!__syncthreads_or((int)!one)) {
+                const uint32_t m = FROM16 ? ((bucket << 16) | kv[0]) : kv[0];
+                const uint32_t out = FROM16 && MAPPED ? unmap_key<uint32_t>(m, neg, pos) : m;
+                if constexpr (FROM16) {
+#pragma unroll
+                    for (int i = 0; i < KPT; ++i) {
+                        const uint32_t idx = (uint32_t)tid + i * BLOCK;
+                        if (idx < cnt) buf[start + idx] = out;
+                    }
+                }
+                continue;
+            }
+        }
         {
             uint4* t4 = reinterpret_cast<uint4*>(tab);
             const uint4 z = {0, 0, 0, 0};
@@ -2529,6 +2632,217 @@ __global__ __launch_bounds__(COUNT16_THREADS) void local_count16_sort_kernel(
             }
         }
         __syncthreads();  // the next bucket clears the table
+    }
+}
+
+// K4 for giants (4-byte keys): buckets of 65 536 keys and more — the reference's bimodal bench input puts half the slice in
+// one, a column of small integers or of floats of one magnitude all of it in a few.  The expanding idea across workgroups:
+// a bucket's sorted form is its count table written out, so the keys are read once (as 16-bit halves) and never moved.
+//   zero     the giants' tables (65 536 u32 counts each, in the workspace)
+//   count    work item = (giant, chunk of 2^19 keys, half of the value range): 32-bit counters for 32 768 values in LDS
+//            (128 KiB), one add per key of that half, then the non-zero counters are added to the giant's table
+//            (<= 32 768 global adds per 2^19 keys read; reading each chunk twice keeps the counters 32 bits wide)
+//   scan     one block per giant: exclusive prefixes in place, the total behind them
+//   expand   work item = (giant, 2^14 output positions): two probes of the table find the values the range spans, that
+//            slice of the prefixes goes to LDS, every position searches it (as many steps as the slice needs: a dense
+//            bucket's range spans a handful of values) and is stored coalesced, key map undone
+// 2 (or 4) + 4 bytes per key.  route_kernel lists the giants and their work items; at most GIANT_MAX tables exist.
+constexpr int GIANT_THREADS = 1024;
+constexpr int GIANT_SLICE = 16383;  // prefixes of a slice in LDS (plus the one behind them)
+constexpr size_t giant_count_lds_bytes() { return 4 * 32768 + 4 * 1040 + 64; }
+constexpr size_t giant_expand_lds_bytes() { return 4 * ((size_t)GIANT_SLICE + 1) + 4 * 1040 + 256; }
+
+__global__ __launch_bounds__(256) void giant_zero_kernel(const Plan* __restrict__ plan, uint32_t* __restrict__ tables) {
+    if (!plan->local_sort || plan->route != ROUTE_HYBRID || plan->giants == 0) return;
+    const uint64_t vecs = (uint64_t)plan->giants * GIANT_TABLE / 4;
+    uint4* t4 = reinterpret_cast<uint4*>(tables);
+    const uint4 z = {0, 0, 0, 0};
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < vecs; i += (uint64_t)gridDim.x * 256) t4[i] = z;
+}
+
+// the giant a work item belongs to: largest g with item0[g] <= it (item0 in LDS, G + 1 entries, item0[G] = all items)
+__device__ __forceinline__ uint32_t giant_of_item(const uint32_t* item0, uint32_t G, uint32_t it) {
+    uint32_t g = 0;
+#pragma unroll
+    for (int b = 10; b >= 0; --b) {
+        const uint32_t c = g | (1u << b);
+        if (c < G && item0[c] <= it) g = c;
+    }
+    return g;
+}
+
+template <bool MAPPED, bool FROM16>
+__global__ __launch_bounds__(GIANT_THREADS) void giant_count_kernel(
+    const uint32_t* __restrict__ buf_keys, const uint32_t* __restrict__ buf_tmp, const uint16_t* __restrict__ src16, const uint32_t* __restrict__ bstart,
+    const Plan* __restrict__ plan, uint32_t neg, uint32_t pos, const uint32_t* __restrict__ glist, const uint32_t* __restrict__ gcount_item,
+    uint32_t* __restrict__ tables) {
+    constexpr int BLOCK = GIANT_THREADS, U = 8;
+    if (!plan->local_sort || plan->route != ROUTE_HYBRID || plan->giants == 0) return;
+    const uint32_t* __restrict__ buf = plan->result_in_tmp ? buf_tmp : buf_keys;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* tab = reinterpret_cast<uint32_t*>(smem);                  // [32768]
+    uint32_t* item0 = reinterpret_cast<uint32_t*>(smem + 4 * 32768);   // [G + 1]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t G = plan->giants, items = plan->giant_count_items;
+    for (uint32_t i = tid; i <= G; i += BLOCK) item0[i] = gcount_item[i];
+    __syncthreads();
+    for (uint32_t it = blockIdx.x; it < items; it += gridDim.x) {
+        const uint32_t g = giant_of_item(item0, G, it);
+        const uint32_t local = it - item0[g], chunk = local >> 1, half = local & 1u;
+        const uint32_t bucket = glist[g], start = bstart[bucket], cnt = bstart[bucket + 1] - start;
+        const uint32_t c0 = chunk * GIANT_CHUNK, c1 = cnt - c0 < GIANT_CHUNK ? cnt : c0 + GIANT_CHUNK;
+        {
+            uint4* t4 = reinterpret_cast<uint4*>(tab);
+            const uint4 z = {0, 0, 0, 0};
+            for (int i = tid; i < 32768 / 4; i += BLOCK) t4[i] = z;
+        }
+        __syncthreads();
+        for (uint32_t base = c0; base < c1; base += BLOCK * U) {  // wave-uniform trip count
+            uint32_t v[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const uint32_t idx = base + (uint32_t)j * BLOCK + (uint32_t)tid;
+                const uint32_t at = idx < c1 ? idx : c1 - 1;
+                if constexpr (FROM16) v[j] = src16[start + at];
+                else v[j] = buf[start + at];
+            }
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const uint32_t idx = base + (uint32_t)j * BLOCK + (uint32_t)tid;
+                const uint32_t x = FROM16 ? v[j] : ((MAPPED ? map_key<uint32_t>(v[j], neg, pos) : v[j]) & 0xFFFFu);
+                const bool mine = idx < c1 && (x >> 15) == half;
+                const uint32_t x0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
+                if (__all((int)(mine && x == x0)) != 0) {  // 64 keys of one value: one add
+                    if (lane == 0) atomicAdd(&tab[x0 & 0x7FFFu], 64u);
+                } else if (mine) {
+                    atomicAdd(&tab[x & 0x7FFFu], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        uint32_t* T = tables + (size_t)g * GIANT_TABLE + half * 32768u;
+        for (int i = tid; i < 32768; i += BLOCK) {
+            const uint32_t c = tab[i];
+            if (c) atomicAdd(&T[i], c);
+        }
+        __syncthreads();  // the next item clears the table
+    }
+}
+
+__global__ __launch_bounds__(GIANT_THREADS) void giant_scan_kernel(const Plan* __restrict__ plan, uint32_t* __restrict__ tables) {
+    if (!plan->local_sort || plan->route != ROUTE_HYBRID || plan->giants == 0) return;
+    __shared__ uint32_t s_wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (uint32_t g = blockIdx.x; g < plan->giants; g += gridDim.x) {
+        uint4* T4 = reinterpret_cast<uint4*>(tables + (size_t)g * GIANT_TABLE) + (size_t)tid * 16;  // my 64 values
+        uint32_t c[64];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const uint4 v = T4[k];
+            c[4 * k] = v.x; c[4 * k + 1] = v.y; c[4 * k + 2] = v.z; c[4 * k + 3] = v.w;
+        }
+        uint32_t run = 0;
+#pragma unroll
+        for (int k = 0; k < 64; ++k) run += c[k];
+        uint32_t incl = run;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(incl, o);
+            if (lane >= o) incl += y;
+        }
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        uint32_t below = incl - run;
+#pragma unroll
+        for (int x = 0; x < GIANT_THREADS / 64; ++x)
+            if (x < wave) below += s_wsum[x];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            uint4 v;
+            v.x = below; below += c[4 * k];
+            v.y = below; below += c[4 * k + 1];
+            v.z = below; below += c[4 * k + 2];
+            v.w = below; below += c[4 * k + 3];
+            T4[k] = v;
+        }
+        if (tid == GIANT_THREADS - 1) tables[(size_t)g * GIANT_TABLE + H16_BINS] = below;  // == the bucket's length
+        __syncthreads();
+    }
+}
+
+template <bool MAPPED>
+__global__ __launch_bounds__(GIANT_THREADS) void giant_expand_kernel(
+    uint32_t* __restrict__ buf_keys, uint32_t* __restrict__ buf_tmp, const uint32_t* __restrict__ bstart, const Plan* __restrict__ plan,
+    uint32_t neg, uint32_t pos, const uint32_t* __restrict__ glist, const uint32_t* __restrict__ gexp_item, const uint32_t* __restrict__ tables) {
+    constexpr int BLOCK = GIANT_THREADS, U = 4;
+    if (!plan->local_sort || plan->route != ROUTE_HYBRID || plan->giants == 0) return;
+    uint32_t* __restrict__ buf = plan->result_in_tmp ? buf_tmp : buf_keys;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* s_p = reinterpret_cast<uint32_t*>(smem);                                          // [GIANT_SLICE + 1]
+    uint32_t* item0 = reinterpret_cast<uint32_t*>(smem + 4 * ((size_t)GIANT_SLICE + 1));        // [G + 1]
+    uint32_t* s_red = reinterpret_cast<uint32_t*>(smem + 4 * ((size_t)GIANT_SLICE + 1) + 4 * 1040);  // [32] wave maxima, [32..33] the two values
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t G = plan->giants, items = plan->giant_expand_items;
+    for (uint32_t i = tid; i <= G; i += BLOCK) item0[i] = gexp_item[i];
+    __syncthreads();
+    for (uint32_t it = blockIdx.x; it < items; it += gridDim.x) {
+        const uint32_t g = giant_of_item(item0, G, it);
+        const uint32_t j = it - item0[g];
+        const uint32_t bucket = glist[g], start = bstart[bucket], cnt = bstart[bucket + 1] - start;
+        const uint32_t o0 = j * GIANT_OUT, o1 = cnt - o0 < GIANT_OUT ? cnt : o0 + GIANT_OUT;
+        const uint32_t* __restrict__ P = tables + (size_t)g * GIANT_TABLE;  // P[v] = keys below value v, P[65536] = cnt
+        // the values of positions o0 and o1 - 1: largest v with P[v] <= position.  Thread t probes P[64 t] ...
+        {
+            const uint32_t p = P[64u * (uint32_t)tid];
+            uint32_t lo = p <= o0 ? (uint32_t)tid : 0u, hi = p <= o1 - 1 ? (uint32_t)tid : 0u;  // (P[0] = 0: thread 0 always qualifies)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const uint32_t a = __shfl_xor(lo, o), b = __shfl_xor(hi, o);
+                lo = a > lo ? a : lo;
+                hi = b > hi ? b : hi;
+            }
+            if (lane == 0) { s_red[wave] = lo; s_red[16 + wave] = hi; }
+            __syncthreads();
+            // ... then wave 0 / wave 1 probe the 64 values of the winning thread
+            if (wave < 2) {
+                uint32_t best = 0;
+                for (int w = 0; w < 16; ++w) best = s_red[16 * wave + w] > best ? s_red[16 * wave + w] : best;
+                const uint32_t target = wave == 0 ? o0 : o1 - 1;
+                const uint32_t v = 64u * best + (uint32_t)lane;
+                const uint64_t ok = __builtin_amdgcn_ballot_w64(P[v] <= target);  // a prefix of the lanes (P is non-decreasing), lane 0 among them
+                if (lane == 0) s_red[32 + wave] = 64u * best + (uint32_t)(63 - __builtin_clzll(ok));
+            }
+            __syncthreads();
+        }
+        const uint32_t v_lo = s_red[32], v_hi = s_red[33];
+        const uint32_t top = bucket << 16;
+        for (uint32_t vs = v_lo; vs <= v_hi; vs += GIANT_SLICE) {
+            const uint32_t len = v_hi - vs + 1 < (uint32_t)GIANT_SLICE ? v_hi - vs + 1 : (uint32_t)GIANT_SLICE;  // values vs .. vs + len - 1
+            for (uint32_t k = tid; k <= len; k += BLOCK) s_p[k] = P[vs + k];
+            __syncthreads();
+            const uint32_t out_lo = o0 > s_p[0] ? o0 : s_p[0], out_hi = o1 < s_p[len] ? o1 : s_p[len];
+            const int steps = 32 - __builtin_clz(len);  // len >= 1
+            for (uint32_t base = out_lo; base < out_hi; base += BLOCK * U) {
+                uint32_t k[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) k[u] = 0;
+                for (int b = steps - 1; b >= 0; --b) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const uint32_t idx = base + (uint32_t)u * BLOCK + (uint32_t)tid;
+                        const uint32_t c = k[u] | (1u << b);
+                        if (c < len && s_p[c] <= idx) k[u] = c;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t idx = base + (uint32_t)u * BLOCK + (uint32_t)tid;
+                    const uint32_t m = top | (vs + k[u]);
+                    if (idx < out_hi) buf[start + idx] = MAPPED ? unmap_key<uint32_t>(m, neg, pos) : m;
+                }
+            }
+            __syncthreads();  // the next slice / item overwrites s_p
+        }
     }
 }
 
@@ -3082,6 +3396,7 @@ struct Tuning {
     bool presample = true;              // a 65 536-key sample before K1h: gross skew goes straight to the LSD route
     bool wide2 = true;                  // 8-byte keys: K4 as two 512-thread blocks per CU (false: one 1024-thread block)
     bool atomic_route = true;           // 4-byte keys: try ROUTE_ATOMIC (no counting read) before anything else
+    bool giants = true;                 // 4-byte keys, hybrid route: buckets of 65 536 keys and more are sorted by the giant kernels (else: LSD route)
     bool chain_routes = true;           // behind a failed atomic route try the hybrid route before the LSD one
     bool expand = true;                 // 4-byte keys: buckets the counting K4 refuses go to the expanding one (any bucket below 65 536 keys)
     bool atomic_wide = true;            // ROUTE_ATOMIC for 8-byte keys too (whole keys in the slots)
@@ -3133,7 +3448,7 @@ struct Layout {
     uint32_t levels, tile, status_bytes;  // status_bytes: 4 or 8 per word
     uint64_t tiles;
     size_t off_err, off_tickets, off_plan, off_hpos, off_hpair, off_h16, off_hpos16, off_status, off_status_near, zero_bytes, off_hist, off_base,
-        off_cbase, off_chains, off_bstart, off_fblist, off_fblist2, off_halves, off_cursor_a, off_cursor_b, off_msd_a, total;
+        off_cbase, off_chains, off_bstart, off_fblist, off_fblist2, off_glist, off_gtables, off_halves, off_cursor_a, off_cursor_b, off_msd_a, total;
     uint32_t msd_cap_a, msd_slices;  // ROUTE_ATOMIC: keys an area of pass A holds; areas per top digit
     uint32_t slot_cap;               // and keys a bucket's slot (pass B's destination) holds
 };
@@ -3145,8 +3460,10 @@ int tile_keys(int cfg, uint32_t elem_bytes) {
     return p.nwaves * 64 * kpt_for(p.kpt8, elem_bytes);
 }
 
+constexpr uint32_t GIANT_MAX = 1024;  // count tables of the hybrid route's giant buckets (256 KiB each)
+
 Layout make_layout(uint64_t n, uint32_t elem_bytes, uint32_t levels, int cfg, uint32_t tile_override = 0, bool want_halves = false,
-                   bool want_msd = false) {
+                   bool want_msd = false, bool want_giants = false) {
     Layout L{};
     L.levels = levels;
     L.tile = tile_override ? tile_override : (uint32_t)tile_keys(cfg, elem_bytes);
@@ -3163,7 +3480,7 @@ Layout make_layout(uint64_t n, uint32_t elem_bytes, uint32_t levels, int cfg, ui
     L.off_cursor_a = o; o += sizeof(uint32_t) * RADIX * MSD_SLICES;         // ROUTE_ATOMIC: claim counters of pass A [slice][digit]: 8 lines per slice ...
     L.off_cursor_b = o; o += sizeof(uint32_t) * (size_t)H16_BINS;           // ... and of pass B (one per bucket)
     L.off_h16 = o; o += sizeof(uint32_t) * (size_t)H16_BINS;              // hybrid route: bucket counts (K1h)
-    L.off_hpos16 = o; o += sizeof(uint64_t) * (size_t)CHAINS * RADIX;     // and its level L-2 counts per position range
+    L.off_hpos16 = o; o += sizeof(uint64_t) * 2 * (size_t)CHAINS * RADIX; // and its level L-2 / level L-1 counts per position range
     L.off_status = o; o += (size_t)L.status_bytes * levels * L.tiles * RADIX;
     L.off_status_near = o; o += (size_t)L.status_bytes * levels * L.tiles * RADIX;
     L.zero_bytes = align_up(o, 16); o = L.zero_bytes;  // everything up to here is cleared per sort
@@ -3175,6 +3492,7 @@ Layout make_layout(uint64_t n, uint32_t elem_bytes, uint32_t levels, int cfg, ui
     L.off_bstart = o; o += sizeof(uint32_t) * ((size_t)H16_BINS + 4);     // hybrid route: bucket starts
     L.off_fblist = o; o += sizeof(uint32_t) * (size_t)H16_BINS;           // buckets the first K4 kernel hands on (count: header word 3)
     L.off_fblist2 = o; o += sizeof(uint32_t) * (size_t)H16_BINS;          // and those the second one hands on (count: header word 5)
+    L.off_glist = o; o += sizeof(uint32_t) * 3 * ((size_t)GIANT_MAX + 16); // giants of the hybrid route: buckets, first counting item, first expanding item
     o = align_up(o, 256);
     L.off_halves = o;                                                       // hybrid route, 4-byte keys: low halves between pass L-1 and K4
     if (want_halves && !want_msd) o += align_up(sizeof(uint16_t) * n, 256);
@@ -3200,6 +3518,13 @@ Layout make_layout(uint64_t n, uint32_t elem_bytes, uint32_t levels, int cfg, ui
         const double slack = mean * 0.01 > 8.0 * __builtin_sqrt(mean) ? mean * 0.01 : 8.0 * __builtin_sqrt(mean);
         L.msd_cap_a = (uint32_t)(((uint64_t)(mean + slack) + 2 * TILE / RADIX + 64) / 64 * 64);
         o += align_up((size_t)elem_bytes * L.msd_cap_a * RADIX * L.msd_slices, 256);
+    }
+    // the giants' count tables: they may use the areas of pass A (dead once the atomic route has failed, and the giant kernels
+    // only run behind the hybrid route's own passes); without areas they get their own space
+    L.off_gtables = L.off_msd_a;
+    if (want_giants) {
+        const size_t need = sizeof(uint32_t) * (size_t)GIANT_TABLE * GIANT_MAX;
+        if (o - L.off_msd_a < need) o = L.off_msd_a + need;
     }
     L.total = align_up(o, 256);
     return L;
@@ -3358,7 +3683,7 @@ int launch_presample(const K* keys, uint64_t n, KeyMap km, Plan* plan, hipStream
 // K1h: the hybrid route's 65 536-bin count (same grid and pieces as K1)
 template <typename K>
 int launch_hist16(const K* keys, uint64_t n, uint32_t blocks, KeyMap km, uint32_t* h16, unsigned long long* hpos16, uint32_t* inversion,
-                  uint32_t* overflow, Plan* plan, hipStream_t s, bool sample_first = true) {
+                  uint32_t* overflow, Plan* plan, hipStream_t s, bool sample_first = true, bool giant = false) {
     const bool aligned = (reinterpret_cast<uintptr_t>(keys) & 15u) == 0;
     const bool mapped = km.neg != 0 || km.pos != 0;
     if (sample_first)
@@ -3371,6 +3696,21 @@ int launch_hist16(const K* keys, uint64_t n, uint32_t blocks, KeyMap km, uint32_
         hipLaunchKernelGGL((hist16_kernel<K, VEC, MAPPED>), dim3(blocks), dim3(HIST_THREADS), lds, s, keys, n, (K)km.neg,  \
                            (K)km.pos, h16, hpos16, inversion, overflow, plan);                                             \
     } while (0)
+#define RDST_H16G(VEC, MAPPED)                                                                                             \
+    do {                                                                                                                   \
+        if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&hist16_kernel<K, VEC, MAPPED, true>), lds)) return rc; \
+        hipLaunchKernelGGL((hist16_kernel<K, VEC, MAPPED, true>), dim3(blocks), dim3(HIST_THREADS), lds, s, keys, n,       \
+                           (K)km.neg, (K)km.pos, h16, hpos16, inversion, overflow, plan);                                  \
+    } while (0)
+    if constexpr (sizeof(K) == 4) {
+        if (giant) {
+            if (aligned) { if (mapped) RDST_H16G(V, true); else RDST_H16G(V, false); }
+            else { if (mapped) RDST_H16G(1, true); else RDST_H16G(1, false); }
+            HIP_TRY(hipGetLastError());
+            return RDST_OK;
+        }
+    }
+#undef RDST_H16G
     if (aligned) { if (mapped) RDST_H16(V, true); else RDST_H16(V, false); }
     else { if (mapped) RDST_H16(1, true); else RDST_H16(1, false); }
 #undef RDST_H16
@@ -3384,10 +3724,15 @@ int launch_hist16(const K* keys, uint64_t n, uint32_t blocks, KeyMap km, uint32_
 constexpr int COUNT_THREADS = RDST_COUNT_THREADS;
 // K4: one workgroup per bucket of the hybrid route.  4-byte keys: the counting kernel, then the generic one
 // over the (normally empty) list of buckets it could not take; 8-byte keys: the generic one over all buckets.
+struct GiantArgs {
+    uint32_t *glist, *gcount_item, *gexp_item, *tables;
+};
+
 template <typename K>
 int launch_local_sort(K* keys, K* tmp, const uint32_t* bstart, const Plan* plan, uint32_t* err, KeyMap km, uint32_t* list,
                       uint32_t* list_count, const uint16_t* src16, int cus, hipStream_t s, const uint32_t* slot_count = nullptr,
-                      uint32_t slot_cap = 0, const K* src_slots = nullptr, uint32_t* list2 = nullptr, uint32_t* list2_count = nullptr) {
+                      uint32_t slot_cap = 0, const K* src_slots = nullptr, uint32_t* list2 = nullptr, uint32_t* list2_count = nullptr,
+                      const GiantArgs* ga = nullptr) {
     constexpr int NW = local_waves(sizeof(K)), KPT = local_kpt(sizeof(K));
     constexpr size_t lds = local_lds_bytes(sizeof(K));
     const bool mapped = km.neg != 0 || km.pos != 0;
@@ -3428,6 +3773,30 @@ int launch_local_sort(K* keys, K* tmp, const uint32_t* bstart, const Plan* plan,
                 else { if (mapped) RDST_EXPAND(true, false); else RDST_EXPAND(false, false); }
 #undef RDST_EXPAND
                 HIP_TRY(hipGetLastError());
+                if (ga) {  // the giants of the hybrid route (route_kernel listed them; none: four launches that return at once)
+                    constexpr size_t clds2 = giant_count_lds_bytes(), xlds = giant_expand_lds_bytes();
+                    hipLaunchKernelGGL(giant_zero_kernel, dim3((uint32_t)cus * 4), dim3(256), 0, s, plan, ga->tables);
+#define RDST_GCOUNT(MAPPED, FROM16)                                                                                                  \
+    do {                                                                                                                             \
+        if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&giant_count_kernel<MAPPED, FROM16>), clds2)) return rc;          \
+        hipLaunchKernelGGL((giant_count_kernel<MAPPED, FROM16>), dim3((uint32_t)cus), dim3(GIANT_THREADS), clds2, s, keys, tmp, src16, \
+                           bstart, plan, (uint32_t)km.neg, (uint32_t)km.pos, ga->glist, ga->gcount_item, ga->tables);               \
+    } while (0)
+                    if (src16) { if (mapped) RDST_GCOUNT(true, true); else RDST_GCOUNT(false, true); }
+                    else { if (mapped) RDST_GCOUNT(true, false); else RDST_GCOUNT(false, false); }
+#undef RDST_GCOUNT
+                    hipLaunchKernelGGL(giant_scan_kernel, dim3((uint32_t)cus), dim3(GIANT_THREADS), 0, s, plan, ga->tables);
+                    if (mapped) {
+                        if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&giant_expand_kernel<true>), xlds)) return rc;
+                        hipLaunchKernelGGL((giant_expand_kernel<true>), dim3((uint32_t)cus * 2), dim3(GIANT_THREADS), xlds, s, keys, tmp, bstart, plan,
+                                           (uint32_t)km.neg, (uint32_t)km.pos, ga->glist, ga->gexp_item, ga->tables);
+                    } else {
+                        if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&giant_expand_kernel<false>), xlds)) return rc;
+                        hipLaunchKernelGGL((giant_expand_kernel<false>), dim3((uint32_t)cus * 2), dim3(GIANT_THREADS), xlds, s, keys, tmp, bstart, plan,
+                                           (uint32_t)km.neg, (uint32_t)km.pos, ga->glist, ga->gexp_item, ga->tables);
+                    }
+                    HIP_TRY(hipGetLastError());
+                }
                 return RDST_OK;  // (the list is spent: nothing is left for the ranked kernel)
             }
         }
@@ -3622,7 +3991,9 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     const bool halves_cfg = g_tuning.halves && g_tuning.count_sort && halves_possible<K>(cfg, n);
     const bool try_hybrid = whole_sort && hybrid_eligible(n, sizeof(K)) && (!try_atomic || (g_tuning.chain_routes && (sizeof(K) == 8 || halves_cfg)));
     const bool halves = try_hybrid && halves_cfg;
-    const Layout L = make_layout(n, sizeof(K), LEVELS, cfg, HAS_V ? PAIR_WAVES * 64 * pair_kpt(sizeof(K), ValBytes<V>::value) : 0, halves, try_atomic);
+    // 4-byte keys: the hybrid route takes buckets of any size (K1h counts them exactly, the giant kernels of K4 sort them)
+    const bool giants = try_hybrid && sizeof(K) == 4 && g_tuning.giants && g_tuning.count_sort && g_tuning.expand && n < (1ull << 30);
+    const Layout L = make_layout(n, sizeof(K), LEVELS, cfg, HAS_V ? PAIR_WAVES * 64 * pair_kpt(sizeof(K), ValBytes<V>::value) : 0, halves, try_atomic, giants);
     if (L.tiles >= (1ull << 31)) return fail(RDST_ERR_ARG, "len too large for one launch");
     rc = ensure_workspace(*D, L.total);
     if (rc) return rc;
@@ -3733,7 +4104,7 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
             uint32_t* overflow = reinterpret_cast<uint32_t*>(ws + L.off_err) + 2;
             uint32_t* h16 = reinterpret_cast<uint32_t*>(ws + L.off_h16);
             unsigned long long* hpos16 = reinterpret_cast<unsigned long long*>(ws + L.off_hpos16);
-            rc = launch_hist16<K>(keys, n, (uint32_t)blocks, km, h16, hpos16, inversion, overflow, plan, s, !try_atomic);
+            rc = launch_hist16<K>(keys, n, (uint32_t)blocks, km, h16, hpos16, inversion, overflow, plan, s, !try_atomic, giants);
             if (rc) return rc;
             if ((rc = prof_mark(*D, s, RDST_STAGE_HIST16))) return rc;
             RouteArgs ra{};
@@ -3749,6 +4120,10 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
             ra.n = n;
             ra.levels = (uint32_t)LEVELS;
             ra.cap = sizeof(K) == 4 && g_tuning.count_sort && g_tuning.expand ? EXPAND_MAX : (uint32_t)local_tile(sizeof(K));
+            ra.giant_max = giants ? GIANT_MAX : 0u;
+            ra.glist = reinterpret_cast<uint32_t*>(ws + L.off_glist);
+            ra.gcount_item = ra.glist + GIANT_MAX + 16;
+            ra.gexp_item = ra.gcount_item + GIANT_MAX + 16;
             ra.mid_tile = ra.cap == EXPAND_MAX && n >= (1u << 24) ? (uint32_t)COUNT16_TILE : 0u;  // (short slices: the test is not worth a wrong guess either way)
             hipLaunchKernelGGL(route_kernel, dim3(1), dim3(1024), 0, s, ra);
             HIP_TRY(hipGetLastError());
@@ -3807,12 +4182,18 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
             // one K4 for both routes: the atomic route's buckets lie in the slots, the hybrid route's at their final place
             // (4-byte keys: as low halves, in the same region of the workspace either way)
             const bool from16 = sizeof(K) == 4 && (try_atomic || halves);
+            GiantArgs ga{};
+            ga.glist = reinterpret_cast<uint32_t*>(ws + L.off_glist);
+            ga.gcount_item = ga.glist + GIANT_MAX + 16;
+            ga.gexp_item = ga.gcount_item + GIANT_MAX + 16;
+            ga.tables = reinterpret_cast<uint32_t*>(ws + L.off_gtables);
             rc = launch_local_sort<K>(keys, tmp, reinterpret_cast<const uint32_t*>(ws + L.off_bstart), plan, D->err_dev, km,
                                       reinterpret_cast<uint32_t*>(ws + L.off_fblist), reinterpret_cast<uint32_t*>(ws + L.off_err) + 3,
                                       from16 ? reinterpret_cast<const uint16_t*>(ws + L.off_halves) : nullptr, D->cus, s,
                                       try_atomic ? reinterpret_cast<const uint32_t*>(ws + L.off_cursor_b) : nullptr, L.slot_cap,
                                       try_atomic && sizeof(K) == 8 ? reinterpret_cast<const K*>(ws + L.off_halves) : nullptr,
-                                      reinterpret_cast<uint32_t*>(ws + L.off_fblist2), reinterpret_cast<uint32_t*>(ws + L.off_err) + 5);
+                                      reinterpret_cast<uint32_t*>(ws + L.off_fblist2), reinterpret_cast<uint32_t*>(ws + L.off_err) + 5,
+                                      giants ? &ga : nullptr);
             if (rc) return rc;
             if ((rc = prof_mark(*D, s, RDST_STAGE_LOCAL))) return rc;
         }
@@ -4073,6 +4454,8 @@ int rdst_hip_set_hybrid(int enabled, uint64_t min_len) {
     g_tuning.presample = enabled != 5;   // 5: no sample before K1h: every hybrid-eligible sort counts all its keys' prefixes first (tests)
     g_tuning.wide2 = enabled != 6;       // 6: 8-byte keys with the one-block-per-CU form of K4 (A/B, tests)
     g_tuning.atomic_route = enabled == 1 || enabled == 8;  // 1: the default (4- and 8-byte keys try the atomic route first); 2..7: the K1h hybrid route for every key width (7: with the default forms of K4)
+    g_tuning.giants = enabled != 11;       // 11: the default without the giant kernels (a bucket of 65 536 keys sends the sort down the LSD route) (A/B, tests)
+    g_tuning.atomic_route = g_tuning.atomic_route || enabled == 11;
     g_tuning.chain_routes = enabled != 10; // 10: the default, but a failed atomic route falls straight to the LSD route (A/B, tests)
     g_tuning.atomic_route = g_tuning.atomic_route || enabled == 10;
     g_tuning.expand = enabled != 9;        // 9: the K1h hybrid route without the expanding K4 (buckets up to one tile; refused buckets to the ranked kernel) (A/B, tests)
@@ -4235,7 +4618,8 @@ uint64_t rdst_hip_workspace_bytes(uint64_t len, uint32_t elem_bytes) {
     if (cfg < 0 || cfg >= kNumPassCfgs) cfg = default_cfg(elem_bytes, len, true);  // the shape with the smaller tiles: an upper bound for every key kind
     const bool msd = atomic_eligible(len, elem_bytes, cfg);
     const bool halves = !msd && elem_bytes == 4 && hybrid_eligible(len, 4) && g_tuning.halves && g_tuning.count_sort && cfg == 4 && len < (1ull << 30);
-    return make_layout(len, elem_bytes, elem_bytes, cfg, 0, halves, msd).total;
+    const bool giants = elem_bytes == 4 && hybrid_eligible(len, 4) && g_tuning.giants && g_tuning.count_sort && g_tuning.expand && len < (1ull << 30);
+    return make_layout(len, elem_bytes, elem_bytes, cfg, 0, halves, msd, giants).total;
 }
 
 int rdst_hip_sort_device(void* dev_keys, void* dev_tmp, uint64_t len, uint32_t elem_bytes, rdst_key_kind kind,

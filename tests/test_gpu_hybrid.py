@@ -15,7 +15,7 @@ TILE = {4: 16896, 8: 16384}  # K4 tile = largest bucket the hybrid route accepts
 
 
 MODES = {"count": 7, "count_whole_keys": 3, "ranked": 2, "wide_one_block": 6, "atomic": True, "atomic_4_only": 8, "no_expand": 9,
-         "atomic_then_lsd": 10}
+         "atomic_then_lsd": 10, "no_giants": 11}
 
 
 @pytest.fixture(params=list(MODES))
@@ -26,7 +26,8 @@ def hybrid(gpu, request):
     same fed with whole keys.  "ranked": the generic ranked passes for every bucket.  "no_expand": without the expanding
     kernel (buckets up to one tile only, refused buckets to the ranked kernel).  "atomic": the library's default — 4- and
     8-byte keys try the atomic route (MSD passes that claim space, no counting read), then the hybrid one, then LSD
-    ("atomic_4_only": 8-byte keys start at the hybrid route; "atomic_then_lsd": no hybrid route behind a failed atomic one)."""
+    ("atomic_4_only": 8-byte keys start at the hybrid route; "atomic_then_lsd": no hybrid route behind a failed atomic one;
+    "no_giants": without the giant kernels — a 4-byte bucket of 65 536 keys and more sends the sort down the LSD route)."""
     gpu.set_hybrid(MODES[request.param], min_len=1)   # consider the routes at every length (default: 2^28 and up)
     gpu._test_mode = request.param
     yield gpu
@@ -36,7 +37,12 @@ def hybrid(gpu, request):
 
 def _takes_atomic(rdst, dtype):
     mode, nb = getattr(rdst, "_test_mode", ""), np.dtype(dtype).itemsize
-    return (mode in ("atomic", "atomic_then_lsd") and nb in (4, 8)) or (mode == "atomic_4_only" and nb == 4)
+    return (mode in ("atomic", "atomic_then_lsd", "no_giants") and nb in (4, 8)) or (mode == "atomic_4_only" and nb == 4)
+
+
+def _giants_ok(rdst, dtype):
+    """4-byte keys, the counting and expanding K4 kernels on: buckets of 65 536 keys and more are the giant kernels'"""
+    return np.dtype(dtype).itemsize == 4 and getattr(rdst, "_test_mode", "") in ("count", "count_whole_keys", "wide_one_block", "atomic", "atomic_4_only")
 
 
 def _bucket_cap(rdst, dtype):
@@ -118,7 +124,7 @@ def test_buckets_up_to_one_tile(hybrid, dtype):
     # demand a correct result here and check the route only when every bucket still fits
     got, route = _sort(hybrid, b)
     top = (mapped_key(b) >> np.array(w - 16, dtype=f"uint{w}")).astype(np.int64)
-    fits = np.bincount(top, minlength=65536).max() <= _bucket_cap(hybrid, dtype)
+    fits = np.bincount(top, minlength=65536).max() <= _bucket_cap(hybrid, dtype) or _giants_ok(hybrid, dtype)
     assert (route == "lsd") if not fits else _fast_route(hybrid, route, dtype, strict=False)
     assert same_bits(got, reference_sorted(b)), dtype
 
@@ -138,7 +144,7 @@ def test_bucket_larger_than_the_routes_bound(hybrid):
         low = random_bits(cap + extra, "uint32", seed=6) & np.uint32(0xFFFF)
         a = np.concatenate([low | np.uint32(0xABCD0000), random_bits(100_000, "uint32", seed=7) & np.uint32(0x7FFFFFFF)])
         got, route = _sort(hybrid, a)
-        assert route == _skewed_route(hybrid, "uint32", not extra), (extra, route)
+        assert route == _skewed_route(hybrid, "uint32", not extra or _giants_ok(hybrid, "uint32")), (extra, route)
         assert same_bits(got, reference_sorted(a))
 
 
@@ -163,25 +169,81 @@ def test_buckets_of_several_tiles_and_of_few_distinct_values(hybrid):
         a = a.view(dtype)
         got, route = _sort(hybrid, a)
         top = (mapped_key(a) >> np.uint32(16)).astype(np.int64)
-        fits = np.bincount(top, minlength=65536).max() <= _bucket_cap(hybrid, dtype)
+        fits = np.bincount(top, minlength=65536).max() <= _bucket_cap(hybrid, dtype) or _giants_ok(hybrid, dtype)
         assert route == _skewed_route(hybrid, dtype, fits), (dtype, route)   # (too skewed for the atomic route's areas in any mode)
         assert same_bits(got, reference_sorted(a)), dtype
 
 
 def test_counter_overflow_in_k1h_is_detected(hybrid):
-    """> 65 535 keys of one bucket inside one block's piece: the packed 16-bit LDS counter carries or wraps;
-    the block-wide sum test must send the sort down the LSD route."""
+    """> 65 535 keys of one bucket inside one block's piece: without the giant kernels the packed 16-bit LDS counter carries
+    or wraps and the block-wide sum test must send the sort down the LSD route; with them (4-byte keys by default) a counter
+    is 15 bits and a guard, every wrap is moved to the global table as it happens, and the hybrid route sorts the bucket."""
     n = 6_000_000
+    want = _skewed_route(hybrid, "uint32", _giants_ok(hybrid, "uint32"))
     for heavy_prefix in (0x1234, 0x1235):   # low and high half of a counter word
         a = random_bits(n, "uint32", seed=8).copy()
         a[: n // 2] = (a[: n // 2] & np.uint32(0xFFFF)) | np.uint32(heavy_prefix << 16)
         np.random.default_rng(9).shuffle(a)
         got, route = _sort(hybrid, a)
-        assert route == "lsd"
+        assert route == want
         assert same_bits(got, reference_sorted(a))
     # 65 536 * k keys in one bucket of one piece: a counter that wraps to exactly 0
     a = np.full(65536 * 4, 0x77770000, dtype=np.uint32) | (random_bits(65536 * 4, "uint32", seed=10) & np.uint32(0xFFFF))
     a = np.concatenate([a, random_bits(50_000, "uint32", seed=11)])
+    got, route = _sort(hybrid, a)
+    assert route == want
+    assert same_bits(got, reference_sorted(a))
+
+
+def test_giant_buckets(hybrid):
+    """4-byte keys: 16-bit prefixes holding 65 536 keys and more — dense and sparse in their low halves, of two values, of one
+    value, neighbours in one counter word, first and last prefix, mapped key kinds, the reference's bimodal bench shape
+    (gen_inputs with shift 16, src/test_utils.rs:51-61) — are sorted by the hybrid route's giant kernels."""
+    rng = np.random.default_rng(2024)
+
+    def bucket(prefix, size, kind):
+        if kind == "dense":
+            low = rng.integers(0, 1 << 16, size=size, dtype=np.uint32)
+        elif kind == "sparse":      # few distinct values far apart: long empty stretches of the count table
+            low = rng.choice(np.array([0, 1, 300, 30000, 32767, 32768, 65000, 65535], dtype=np.uint32), size=size)
+        elif kind == "two":
+            low = rng.choice(np.array([0, 65535], dtype=np.uint32), size=size)
+        elif kind == "one":
+            low = np.full(size, 0x8000, dtype=np.uint32)
+        else:                        # "narrow": every value of a small range, many times
+            low = rng.integers(1000, 1100, size=size, dtype=np.uint32)
+        return low | np.uint32(prefix << 16)
+
+    for dtype in ("uint32", "int32", "float32"):
+        parts = [bucket(0x0000, 65_536, "dense"), bucket(0xFFFF, 70_001, "sparse"), bucket(0x1234, 300_000, "dense"),
+                 bucket(0x1235, 65_537, "two"), bucket(0x8000, 131_072, "one"), bucket(0x7FFF, 1_100_000, "narrow"),
+                 bucket(0x4000, 65_535, "dense"), bucket(0x4001, 20_000, "two"), random_bits(500_000, "uint32", seed=5)]
+        a = np.concatenate(parts)
+        rng.shuffle(a)
+        a = a.view(dtype)
+        got, route = _sort(hybrid, a)
+        assert route == _skewed_route(hybrid, dtype, _giants_ok(hybrid, dtype)), (dtype, route)
+        assert same_bits(got, reference_sorted(a)), dtype
+    # bimodal: half the keys below 2^16 (one giant bucket), the other half with their low 16 bits zero (buckets of one value)
+    r = random_bits(4_000_000, "uint32", seed=6)
+    a = np.concatenate([r[:2_000_000] >> np.uint32(16), r[2_000_000:] << np.uint32(16)])
+    got, route = _sort(hybrid, a)
+    assert route == _skewed_route(hybrid, "uint32", _giants_ok(hybrid, "uint32"))
+    assert same_bits(got, reference_sorted(a))
+    # every key in one bucket; and in one bucket and one value but for a few
+    for a in (random_bits(3_000_000, "uint32", seed=7) & np.uint32(0xFFFF) | np.uint32(0x00420000),
+              np.where(np.arange(2_000_000) % 100_003 == 0, np.uint32(7), np.uint32(0x00420042)).astype(np.uint32)):
+        got, route = _sort(hybrid, a)
+        assert route == _skewed_route(hybrid, "uint32", _giants_ok(hybrid, "uint32"))
+        assert same_bits(got, reference_sorted(a))
+
+
+def test_more_giants_than_tables_take_the_lsd_route(hybrid):
+    if hybrid._test_mode not in ("atomic", "count", "no_giants"):
+        pytest.skip("137 M keys: three modes are enough")
+    a = (np.arange(2100 * 65_536, dtype=np.uint32) * np.uint32(2654435761)) & np.uint32(0x07FFFFFF)   # 2 048 prefixes, 67 000 keys each or so
+    top = np.bincount((a >> np.uint32(16)).astype(np.int64), minlength=65536)
+    assert (top >= 65536).sum() > 1024 or not _giants_ok(hybrid, "uint32")
     got, route = _sort(hybrid, a)
     assert route == "lsd"
     assert same_bits(got, reference_sorted(a))
