@@ -679,7 +679,13 @@ struct RouteArgs {
     uint32_t* gexp_item;    // [giant_max + 1] out: first work item of each in the expanding kernel (one per GIANT_OUT positions)
 };
 constexpr uint32_t GIANT_MIN = 65536;      // keys: below it the 16-bit counters of the LDS kernels do
-constexpr uint32_t GIANT_CHUNK = 1u << 19; // keys a block of the giant counting kernel streams per item (and value half)
+constexpr uint32_t GIANT_CHUNK = 1u << 19; // keys a block of the giant counting kernel streams per item (and value half), at least
+// chunk of a giant of cnt keys: at most 128 chunks — every item ends with up to 32 768 adds to the giant's ONE table, and a
+// 10^9-key giant cut into 2^19-key chunks spent a third of its time on those (125 M adds on 65 536 addresses)
+__host__ __device__ inline uint32_t giant_chunk_of(uint32_t cnt) {
+    const uint32_t c = ((cnt + 127u) / 128u + 8191u) & ~8191u;
+    return c > GIANT_CHUNK ? c : GIANT_CHUNK;
+}
 constexpr uint32_t GIANT_OUT = 1u << 14;   // positions a block of the giant expanding kernel writes per item
 constexpr uint32_t GIANT_TABLE = H16_BINS + 16;  // words per giant: 65 536 counts / prefixes, then the total
 
@@ -703,7 +709,7 @@ __global__ __launch_bounds__(1024) void route_kernel(RouteArgs a) {
         else sum1 += c[k];
         if (giants_ok && c[k] >= GIANT_MIN) {
             ++ng;
-            nci += 2u * ((c[k] + GIANT_CHUNK - 1) / GIANT_CHUNK);
+            nci += 2u * ((c[k] + giant_chunk_of(c[k]) - 1) / giant_chunk_of(c[k]));
             nei += (c[k] + GIANT_OUT - 1) / GIANT_OUT;
         } else {
             mx = c[k] > mx ? c[k] : mx;
@@ -756,7 +762,7 @@ __global__ __launch_bounds__(1024) void route_kernel(RouteArgs a) {
                 a.gcount_item[eg] = eci;
                 a.gexp_item[eg] = eei;
                 ++eg;
-                eci += 2u * ((c[k] + GIANT_CHUNK - 1) / GIANT_CHUNK);
+                eci += 2u * ((c[k] + giant_chunk_of(c[k]) - 1) / giant_chunk_of(c[k]));
                 eei += (c[k] + GIANT_OUT - 1) / GIANT_OUT;
             }
         }
@@ -926,7 +932,9 @@ __global__ __launch_bounds__(256 * SCAN_GROUPS) void scan_kernel(ScanArgs a) {
                 in_tmp ^= 1u; ++executed; prev = (int)l;
             }
         }
-        a.plan->result_in_tmp = in_tmp;
+        // (hybrid route with the 16-bit hand-off: K4 reads the halves from the workspace and writes whole keys — to the caller's
+        // array, whichever buffer the last pass read: no copy-back even after an odd number of passes)
+        a.plan->result_in_tmp = hybrid && a.halves ? 0u : in_tmp;
         a.plan->executed = executed;
     }
     __syncthreads();
@@ -2263,23 +2271,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 8 : 6) void local_count_sort
 #pragma unroll
     for (int k = 0; k < WPT; ++k) cnt4[k * BLOCK + tid] = 0;
     if (tid == 0) s_wsum[16] = 0;
-    // a bucket of ONE value (bimodal input: every key of the shifted half) needs no sorting, and would overflow the counters
-    bool differ = false;
-    {
-        const uint32_t first = FROM16 ? (uint32_t)src16[soff] : buf[start];
-#pragma unroll
-        for (int i = 0; i < MAXR; ++i) differ |= kv[i] != first;  // (slots past cnt repeat the last key)
-    }
-    if (!__syncthreads_or((int)differ)) {
-        const uint32_t m = FROM16 ? ((bucket << 16) | kv[0]) : kv[0];
-        const uint32_t out = FROM16 && MAPPED ? unmap_key<uint32_t>(m, neg, pos) : m;
-#pragma unroll
-        for (int i = 0; i < MAXR; ++i) {
-            const uint32_t idx = (uint32_t)tid + i * BLOCK;
-            if (idx < cnt && (FROM16 || slot_count)) buf[start + idx] = out;  // (whole keys in place are where they belong already)
-        }
-        return;
-    }
+    __syncthreads();
     __builtin_amdgcn_s_setprio(0);
     auto word_of = [](uint32_t v) -> uint32_t { return ((v >> 3) & (uint32_t)(WPT - 1)) * BLOCK + (v >> LOG_VPT); };
     bool over = false;
@@ -2297,7 +2289,29 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 8 : 6) void local_count_sort
     }
     if (over) s_wsum[16] = 1;
     __syncthreads();
-    if (s_wsum[16]) {  // block-uniform: the bucket stays as it is, for the generic kernel
+    if (s_wsum[16]) {  // block-uniform: a value 16 times
+        // one value only (the bimodal bench input: every bucket of the shifted half)?  Then the bucket is written at once ...
+        bool differ = false;
+        const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)kv[0]) & 0xFFFFu;  // (kv: value | index << 16 by now)
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i) {
+            const uint32_t idx = (uint32_t)tid + i * BLOCK;
+            if (idx < cnt) differ |= (kv[i] & 0xFFFFu) != first;
+        }
+        if (tid == 0) s_wsum[17] = first;
+        const int any = __syncthreads_or((int)differ);       // every wave of one value ...
+        const bool agree = first == s_wsum[17] || (uint32_t)(tid & ~63) >= cnt;
+        if (!any && !__syncthreads_or((int)!agree)) {       // ... and the same one
+            const uint32_t m = (bucket << 16) | first;
+            const uint32_t out = MAPPED ? unmap_key<uint32_t>(m, neg, pos) : m;
+#pragma unroll
+            for (int i = 0; i < MAXR; ++i) {
+                const uint32_t idx = (uint32_t)tid + i * BLOCK;
+                if (idx < cnt) buf[start + idx] = out;
+            }
+            return;
+        }
+        // ... else it stays as it is, for the next kernel
         if (tid == 0) list[atomicAdd(list_count, 1u)] = bucket;
         return;
     }
@@ -2506,13 +2520,15 @@ __global__ __launch_bounds__(COUNT16_THREADS) void local_count16_sort_kernel(
     auto word_of = [](uint32_t v) -> uint32_t { return (v >> 1) + (v >> 6); };
     const uint32_t total = *list_count;
     // the keys of the next bucket are fetched while this one is sorted (one block per CU: nothing else hides the latency)
-    uint32_t nxt[KPT];
+    uint32_t nxt[KPT], nxt_first = 0;
     auto fetch = [&](uint32_t e) {
         if (e >= total) return;
         const uint32_t bucket = list[e];
         const uint32_t start = bstart[bucket], cnt = slot_count ? slot_count[bucket] : bstart[bucket + 1] - start;
         const uint32_t soff = slot_count ? bucket * slot_cap : start;
         if (cnt > (uint32_t)COUNT16_TILE || cnt == 0) return;
+        if constexpr (FROM16) nxt_first = src16[soff];
+        else nxt_first = buf[start];
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
             const uint32_t idx = (uint32_t)tid + i * BLOCK;
@@ -2533,26 +2549,23 @@ __global__ __launch_bounds__(COUNT16_THREADS) void local_count16_sort_kernel(
         uint32_t kv[KPT];
 #pragma unroll
         for (int i = 0; i < KPT; ++i) kv[i] = nxt[i];
+        const uint32_t first = nxt_first;
         // (in place — not FROM16, the hybrid route fed with whole keys — the next bucket is another range of buf: no hazard)
         fetch(e + gridDim.x);
-        {   // a bucket of one value: written at once (its 64-key waves would each add once, but the table work is the cost)
+        {   // a bucket of one value (the bimodal bench input: every bucket of the shifted half) is written at once
             bool differ = false;
-            const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)kv[0]);  // every wave's lane 0 holds a key of the bucket's first 1 024
 #pragma unroll
-            for (int i = 0; i < KPT; ++i) differ |= kv[i] != first;
-            if (tid == 0) s_wsum[16] = kv[0];
-            const int any = __syncthreads_or((int)differ);
-            const bool one = !any && first == s_wsum[16];  // each wave is constant: and they agree (every wave with a key compares with wave 0's)
-            if (!__syncthreads_or((int)!one)) {
-                const uint32_t m = FROM16 ? ((bucket << 16) | kv[0]) : kv[0];
-                const uint32_t out = FROM16 && MAPPED ? unmap_key<uint32_t>(m, neg, pos) : m;
+            for (int i = 0; i < KPT; ++i) differ |= kv[i] != first;  // (slots past cnt repeat the last key)
+            if (!__syncthreads_or((int)differ)) {
                 if constexpr (FROM16) {
+                    const uint32_t m = (bucket << 16) | first;
+                    const uint32_t out = MAPPED ? unmap_key<uint32_t>(m, neg, pos) : m;
 #pragma unroll
                     for (int i = 0; i < KPT; ++i) {
                         const uint32_t idx = (uint32_t)tid + i * BLOCK;
                         if (idx < cnt) buf[start + idx] = out;
                     }
-                }
+                }  // (whole keys in place are where they belong already)
                 continue;
             }
         }
@@ -2690,21 +2703,50 @@ __global__ __launch_bounds__(GIANT_THREADS) void giant_count_kernel(
         const uint32_t g = giant_of_item(item0, G, it);
         const uint32_t local = it - item0[g], chunk = local >> 1, half = local & 1u;
         const uint32_t bucket = glist[g], start = bstart[bucket], cnt = bstart[bucket + 1] - start;
-        const uint32_t c0 = chunk * GIANT_CHUNK, c1 = cnt - c0 < GIANT_CHUNK ? cnt : c0 + GIANT_CHUNK;
+        const uint32_t ck = giant_chunk_of(cnt);
+        const uint32_t c0 = chunk * ck, c1 = cnt - c0 < ck ? cnt : c0 + ck;
         {
             uint4* t4 = reinterpret_cast<uint4*>(tab);
             const uint4 z = {0, 0, 0, 0};
             for (int i = tid; i < 32768 / 4; i += BLOCK) t4[i] = z;
         }
         __syncthreads();
+        if constexpr (FROM16) {
+            // eight halves per load (16 bytes per lane, as every streaming kernel here): with 2-byte loads the kernel ran at 2 TB/s
+            constexpr int U2 = 4;
+            const uint64_t g0 = (uint64_t)start + c0, g1 = (uint64_t)start + c1;  // element range in src16 (16-byte aligned base)
+            for (uint64_t base = g0 & ~7ull; base < g1; base += (uint64_t)BLOCK * 8 * U2) {  // wave-uniform trip count
+                uint4 q[U2];
+#pragma unroll
+                for (int j = 0; j < U2; ++j) {
+                    const uint64_t p = base + ((uint64_t)j * BLOCK + (uint64_t)tid) * 8;
+                    q[j] = p < g1 ? *reinterpret_cast<const uint4*>(src16 + p) : uint4{0, 0, 0, 0};
+                }
+#pragma unroll
+                for (int j = 0; j < U2; ++j) {
+                    const uint64_t p = base + ((uint64_t)j * BLOCK + (uint64_t)tid) * 8;
+                    const uint32_t w[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const uint32_t x = (w[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu;
+                        const bool mine = p + e >= g0 && p + e < g1 && (x >> 15) == half;
+                        const uint32_t x0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
+                        if (__all((int)(mine && x == x0)) != 0) {
+                            if (lane == 0) atomicAdd(&tab[x0 & 0x7FFFu], 64u);
+                        } else if (mine) {
+                            atomicAdd(&tab[x & 0x7FFFu], 1u);
+                        }
+                    }
+                }
+            }
+        } else
         for (uint32_t base = c0; base < c1; base += BLOCK * U) {  // wave-uniform trip count
             uint32_t v[U];
 #pragma unroll
             for (int j = 0; j < U; ++j) {
                 const uint32_t idx = base + (uint32_t)j * BLOCK + (uint32_t)tid;
                 const uint32_t at = idx < c1 ? idx : c1 - 1;
-                if constexpr (FROM16) v[j] = src16[start + at];
-                else v[j] = buf[start + at];
+                v[j] = buf[start + at];
             }
 #pragma unroll
             for (int j = 0; j < U; ++j) {
