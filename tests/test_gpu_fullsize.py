@@ -1,9 +1,3 @@
-def test_skewed_full_size_inputs_and_gross_skew_skips_the_first_pass(gpu):
-    """The reference's bimodal bench input (gen_inputs with shift 16, src/test_utils.rs:51-61 / benches/full_sort.rs:68-78) at
-    5·10^8 keys: half the keys share the 16-bit prefix 0 — the 8 192-key sample sees it, the byte-saving routes' first kernels
-    (pass A of the atomic route; K1h of the hybrid one) return at once and the LSD route sorts; an input with ONE bucket one key
-    over the tile is invisible to the sample and is caught by the atomic route's own exact check (a slot claim that does not
-    fit): the hybrid route — exact counts, the expanding K4 for that bucket — takes it."""
 """BASELINE.json's full sizes (configs[1..3]: 1 B u32 / u64 / f32 on one MI355X) through
 size-independent properties: the output is non-decreasing in mapped-key order, it is the same
 multiset as the input (two independent checksums + every level's 256-bin histogram is
@@ -103,11 +97,12 @@ def test_more_than_2_pow_30_keys_uses_wide_status_words(gpu):
     assert _is_sorted(torch, keys ^ torch.iinfo(torch.int32).min)
 
 
-def test_skewed_full_size_inputs_take_the_lsd_route_and_gross_skew_skips_the_first_pass(gpu):
+def test_skewed_full_size_inputs(gpu):
     """The reference's bimodal bench input (gen_inputs with shift 16, src/test_utils.rs:51-61 / benches/full_sort.rs:68-78) at
-    5·10^8 keys: half the keys share the 16-bit prefix 0 — the 8 192-key sample sees it and the byte-saving route's first kernel
-    (pass A of the atomic route; K1h of the hybrid one) returns at once; an input with ONE bucket one key over the tile is
-    invisible to the sample and must be caught by the route's own exact check (a slot claim that does not fit; K1h's counts)."""
+    5·10^8 keys: half the keys share the 16-bit prefix 0.  The 8 192-key sample sees it: pass A of the atomic route returns at
+    once; K1h counts the slice exactly (a bucket of any size), the hybrid route's giant kernels sort that bucket and the
+    buckets of one value the other half makes are written at once.  An input with ONE bucket one key over the tile is invisible
+    to the sample and is caught by the atomic route's own exact check (a slot claim that does not fit): the hybrid route takes it."""
     import torch
     n = 500_000_000
     src = _gen(torch, n, torch.int32, 0x5D570008)
@@ -117,7 +112,7 @@ def test_skewed_full_size_inputs_take_the_lsd_route_and_gross_skew_skips_the_fir
     for mode, first in ((True, "msd_pass_a"), (7, "histogram16")):
         gpu.set_hybrid(mode)
         try:
-            for name, inp, first_runs, route in (("bimodal", bimodal, False, "lsd"), ("borderline", borderline, True, "hybrid")):
+            for name, inp, first_runs, route in (("bimodal", bimodal, first == "histogram16", "hybrid"), ("borderline", borderline, True, "hybrid")):
                 keys = inp.clone()
                 gpu.sort_device_tensor(keys.view(torch.uint32))   # first use of a kernel loads its code object: not timed
                 keys.copy_(inp)
