@@ -680,13 +680,16 @@ struct RouteArgs {
 };
 constexpr uint32_t GIANT_MIN = 65536;      // keys: below it the 16-bit counters of the LDS kernels do
 constexpr uint32_t GIANT_CHUNK = 1u << 19; // keys a block of the giant counting kernel streams per item (and value half), at least
-// chunk of a giant of cnt keys: at most 128 chunks — every item ends with up to 32 768 adds to the giant's ONE table, and a
-// 10^9-key giant cut into 2^19-key chunks spent a third of its time on those (125 M adds on 65 536 addresses)
-__host__ __device__ inline uint32_t giant_chunk_of(uint32_t cnt) {
-    const uint32_t c = ((cnt + 127u) / 128u + 8191u) & ~8191u;
+// chunk of a giant of cnt keys when the sort has `giants` of them: about 256 chunks in all and never more than 128 per giant —
+// every item ends with up to 32 768 adds to the giant's table (a 10^9-key giant cut into 2^19-key chunks spent a third of its
+// time on 125 M of them; 1 800 giants of 10^6 keys likewise), and a giant that is ONE chunk needs no adds at all: its two
+// items (the halves of the value range) store their counters
+__host__ __device__ inline uint32_t giant_chunk_of(uint32_t cnt, uint32_t giants) {
+    const uint32_t parts = giants >= 256u ? 1u : (256u / giants > 128u ? 128u : 256u / giants);
+    const uint32_t c = ((cnt + parts - 1u) / parts + 8191u) & ~8191u;
     return c > GIANT_CHUNK ? c : GIANT_CHUNK;
 }
-constexpr uint32_t GIANT_OUT = 1u << 14;   // positions a block of the giant expanding kernel writes per item
+constexpr uint32_t GIANT_OUT = 1u << 12;   // positions a block of the giant expanding kernel writes per item
 constexpr uint32_t GIANT_TABLE = H16_BINS + 16;  // words per giant: 65 536 counts / prefixes, then the total
 
 __global__ __launch_bounds__(1024) void route_kernel(RouteArgs a) {
@@ -702,18 +705,13 @@ __global__ __launch_bounds__(1024) void route_kernel(RouteArgs a) {
     }
     const bool giants_ok = a.giant_max != 0;
     uint32_t sum0 = 0, sum1 = 0, mx = 0;  // mx: the largest bucket the LDS kernels of K4 would have to take
-    uint32_t ng = 0, nci = 0, nei = 0;    // my giants, their counting and expanding work items
+    uint32_t ng = 0;                      // my giants
 #pragma unroll
     for (int k = 0; k < 64; ++k) {
         if (k < 32) sum0 += c[k];
         else sum1 += c[k];
-        if (giants_ok && c[k] >= GIANT_MIN) {
-            ++ng;
-            nci += 2u * ((c[k] + giant_chunk_of(c[k]) - 1) / giant_chunk_of(c[k]));
-            nei += (c[k] + GIANT_OUT - 1) / GIANT_OUT;
-        } else {
-            mx = c[k] > mx ? c[k] : mx;
-        }
+        if (giants_ok && c[k] >= GIANT_MIN) ++ng;
+        else mx = c[k] > mx ? c[k] : mx;
     }
     const uint32_t mine = sum0 + sum1;
     uint32_t mid = 0;  // keys in buckets over the middle kernel's tile (they cannot pass 2^32 in sum: n < 2^32)
@@ -721,25 +719,50 @@ __global__ __launch_bounds__(1024) void route_kernel(RouteArgs a) {
 #pragma unroll
         for (int k = 0; k < 64; ++k) mid += (c[k] > a.mid_tile && !(giants_ok && c[k] >= GIANT_MIN)) ? c[k] : 0u;
     }
-    uint32_t incl = mine, wmax = mx, ig = ng, ici = nci, iei = nei;
+    uint32_t incl = mine, wmax = mx, ig = ng;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t y = __shfl_up(incl, o), yg = __shfl_up(ig, o), yc = __shfl_up(ici, o), ye = __shfl_up(iei, o);
-        if (lane >= o) { incl += y; ig += yg; ici += yc; iei += ye; }
+        const uint32_t y = __shfl_up(incl, o), yg = __shfl_up(ig, o);
+        if (lane >= o) { incl += y; ig += yg; }
         const uint32_t m = __shfl_xor(wmax, o);
         wmax = m > wmax ? m : wmax;
         mid += __shfl_xor(mid, o);
     }
-    if (lane == 63) { s_wsum[wave] = incl; s_wg[wave] = ig; s_wci[wave] = ici; s_wei[wave] = iei; }
+    if (lane == 63) { s_wsum[wave] = incl; s_wg[wave] = ig; }
     if (lane == 0) { s_wmax[wave] = wmax; s_wmid[wave] = mid; }
     __syncthreads();
-    uint32_t excl = incl - mine, bmax = 0, eg = ig - ng, eci = ici - nci, eei = iei - nei, tg = 0, tci = 0, tei = 0;
+    uint32_t excl = incl - mine, bmax = 0, eg = ig - ng, tg = 0;
     uint64_t bmid = 0;
     for (int w = 0; w < 16; ++w) {
-        if (w < wave) { excl += s_wsum[w]; eg += s_wg[w]; eci += s_wci[w]; eei += s_wei[w]; }
+        if (w < wave) { excl += s_wsum[w]; eg += s_wg[w]; }
         bmax = s_wmax[w] > bmax ? s_wmax[w] : bmax;
         bmid += s_wmid[w];
-        tg += s_wg[w]; tci += s_wci[w]; tei += s_wei[w];
+        tg += s_wg[w];
+    }
+    // the giants' work items (the chunking depends on how many giants there are: a second scan)
+    uint32_t nci = 0, nei = 0;
+    if (ng) {
+#pragma unroll
+        for (int k = 0; k < 64; ++k) {
+            if (c[k] >= GIANT_MIN) {
+                const uint32_t ck = giant_chunk_of(c[k], tg);
+                nci += 2u * ((c[k] + ck - 1) / ck);
+                nei += (c[k] + GIANT_OUT - 1) / GIANT_OUT;
+            }
+        }
+    }
+    uint32_t ici = nci, iei = nei;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t yc = __shfl_up(ici, o), ye = __shfl_up(iei, o);
+        if (lane >= o) { ici += yc; iei += ye; }
+    }
+    if (lane == 63) { s_wci[wave] = ici; s_wei[wave] = iei; }
+    __syncthreads();
+    uint32_t eci = ici - nci, eei = iei - nei, tci = 0, tei = 0;
+    for (int w = 0; w < 16; ++w) {
+        if (w < wave) { eci += s_wci[w]; eei += s_wei[w]; }
+        tci += s_wci[w]; tei += s_wei[w];
     }
     // the expanding kernel costs ~7 ns per 1 000 keys; the LSD route costs ~3.4 more than the hybrid one per 1 000 keys of the
     // slice: with more than a third of the keys in such buckets the LSD route is the faster one
@@ -762,7 +785,7 @@ __global__ __launch_bounds__(1024) void route_kernel(RouteArgs a) {
                 a.gcount_item[eg] = eci;
                 a.gexp_item[eg] = eei;
                 ++eg;
-                eci += 2u * ((c[k] + giant_chunk_of(c[k]) - 1) / giant_chunk_of(c[k]));
+                eci += 2u * ((c[k] + giant_chunk_of(c[k], tg) - 1) / giant_chunk_of(c[k], tg));
                 eei += (c[k] + GIANT_OUT - 1) / GIANT_OUT;
             }
         }
@@ -1322,6 +1345,28 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8,
         const uint32_t d0 = digit_of(mk[0], shift);
         const uint32_t dn = (uint32_t)__builtin_amdgcn_mov_dpp((int)d0, 0x138, 0xf, 0xf, false);  // lane - 1's digit
         careful = __builtin_popcountll(__builtin_amdgcn_ballot_w64(d0 == dn) & ~1ull) >= 8;
+        // ONE heavy digit (a float column's sign-and-exponent byte: three keys in four; the bimodal input's zero bytes) does
+        // not need the ballots: the lanes that hold it are one ballot away from their ranks (lane order), one of them adds the
+        // group's size, and the other lanes — few, spread over the other digits — use the returning add of the fast form.
+        // Chosen when a quarter of the first round holds the digit of one of three probed lanes and the rest of the round
+        // does not look repetitive itself; everything else that looks repetitive stays on the careful path.
+        bool heavy = false;   // wave-uniform
+        uint32_t hd = 0;      // the heavy digit
+        // (Not in the persistent form of the kernel: the loop already spills there, and this path tripled it — every pass of the
+        // fallback behind the atomic route got 0.1-0.2 ms slower for the one level of a float column it makes 0.3-0.8 ms faster.)
+        if constexpr (CAN_FAST && !PERSIST) {
+            if (careful && full && (ablate & RDST_FAST_RANK) && !RDST_ABL(3)) {
+                uint32_t best = 0;
+#pragma unroll
+                for (int probe = 0; probe < 3; ++probe) {
+                    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)d0, probe * 21);
+                    const uint32_t k = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(d0 == c));
+                    if (k > best) { best = k; hd = c; }
+                }
+                const uint64_t rest_rep = __builtin_amdgcn_ballot_w64(d0 == dn && d0 != hd) & ~1ull;
+                if (best >= 16 && __builtin_popcountll(rest_rep) < 8) { heavy = true; careful = false; }
+            }
+        }
         if constexpr (CAN_FAST) fast = !careful && full && (ablate & RDST_FAST_RANK) && !RDST_ABL(3);
         if (careful) {
 #pragma unroll
@@ -1334,6 +1379,28 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8,
                     uint32_t total;
                     const uint32_t below = peers_below_total(digit_word<K>(mk[i], shift), bit0, total);
                     if (below == 0) atomicAdd(&wh[d], total);
+                }
+            }
+        } else if (fast && heavy) {
+            if constexpr (CAN_FAST && !PERSIST) {
+#pragma unroll
+                for (int i = 0; i < KPT; ++i) {
+                    const uint32_t d = digit_of(mk[i], shift);
+                    const uint64_t m = __builtin_amdgcn_ballot_w64(d == hd);
+                    uint32_t r;
+                    if (m != 0) {  // wave-uniform
+                        const int leader = __builtin_ctzll(m);
+                        uint32_t b = 0;
+                        if (lane == leader) b = atomicAdd(&wh[hd], (uint32_t)__builtin_popcountll(m));
+                        b = (uint32_t)__builtin_amdgcn_readlane((int)b, leader);
+                        const uint32_t within = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                        r = d == hd ? b + within : atomicAdd(&wh[d], 1u);
+                    } else {
+                        r = atomicAdd(&wh[d], 1u);
+                    }
+                    asm volatile("" : "+v"(r));  // finish the round here: its ballot is an SGPR pair, 22 of them alive at once spill
+                    if (i & 1) run_index[i >> 1] |= r << 16;
+                    else run_index[i >> 1] = r;
                 }
             }
         } else if (fast) {
@@ -1634,7 +1701,10 @@ ranked:
 // ------------------------------------------------------------------------------------------
 // SECOND: pass B (sources are pass A's areas, destinations the bucket slots); HALVES: 4-byte keys' pass B stores low halves.
 template <typename K, int KPT, int NWAVES, bool MAPPED, bool SECOND, bool HALVES>
-__global__ __launch_bounds__(NWAVES * 64, (2 * NWAVES + 3) / 4) void msd_scatter_kernel(
+#ifndef RDST_MSD_MINWAVES
+#define RDST_MSD_MINWAVES ((2 * NWAVES + 3) / 4)  // two blocks per CU
+#endif
+__global__ __launch_bounds__(NWAVES * 64, RDST_MSD_MINWAVES) void msd_scatter_kernel(
     const K* __restrict__ src, const uint32_t* __restrict__ area_count /* nullable: one area of n keys */, uint64_t n, uint32_t area_cap,
     uint32_t tiles_per_area, K* __restrict__ dst, uint16_t* __restrict__ dst16, uint32_t* __restrict__ cursor, uint32_t dst_cap, int shift,
     uint32_t slices /* areas per top digit (pass A: of the destination, pass B: of the source) */,
@@ -1649,8 +1719,8 @@ __global__ __launch_bounds__(NWAVES * 64, (2 * NWAVES + 3) / 4) void msd_scatter
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* wave_hist = reinterpret_cast<uint32_t*>(smem);                           // [NWAVES][256]
     uint32_t* s_delta = reinterpret_cast<uint32_t*>(smem + NWAVES * 1024);             // [256] destination of tile slot 0 of a digit's run (elements, mod 2^32)
-    uint32_t* s_misc = reinterpret_cast<uint32_t*>(smem + NWAVES * 1024 + 1024);       // [16]
-    K* s_keys = reinterpret_cast<K*>(smem + NWAVES * 1024 + 1024 + 64);                // [TILE]
+    uint32_t* s_misc = reinterpret_cast<uint32_t*>(smem + NWAVES * 1024 + 1024);       // [32]
+    K* s_keys = reinterpret_cast<K*>(smem + NWAVES * 1024 + 1024 + 128);               // [TILE]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t area = blockIdx.x / tiles_per_area, j = blockIdx.x % tiles_per_area;
     const uint64_t acount = area_count ? (uint64_t)area_count[area] : n;
@@ -2661,9 +2731,8 @@ __global__ __launch_bounds__(COUNT16_THREADS) void local_count16_sort_kernel(
 //            bucket's range spans a handful of values) and is stored coalesced, key map undone
 // 2 (or 4) + 4 bytes per key.  route_kernel lists the giants and their work items; at most GIANT_MAX tables exist.
 constexpr int GIANT_THREADS = 1024;
-constexpr int GIANT_SLICE = 16383;  // prefixes of a slice in LDS (plus the one behind them)
-constexpr size_t giant_count_lds_bytes() { return 4 * 32768 + 4 * 1040 + 64; }
-constexpr size_t giant_expand_lds_bytes() { return 4 * ((size_t)GIANT_SLICE + 1) + 4 * 1040 + 256; }
+constexpr int GIANT_ITEMS_LDS = 4096 + 16;  // first work item of every giant (GIANT_MAX + 1 entries)
+constexpr size_t giant_count_lds_bytes() { return 4 * 32768 + 4 * ((size_t)GIANT_ITEMS_LDS) + 64; }
 
 __global__ __launch_bounds__(256) void giant_zero_kernel(const Plan* __restrict__ plan, uint32_t* __restrict__ tables) {
     if (!plan->local_sort || plan->route != ROUTE_HYBRID || plan->giants == 0) return;
@@ -2677,7 +2746,7 @@ __global__ __launch_bounds__(256) void giant_zero_kernel(const Plan* __restrict_
 __device__ __forceinline__ uint32_t giant_of_item(const uint32_t* item0, uint32_t G, uint32_t it) {
     uint32_t g = 0;
 #pragma unroll
-    for (int b = 10; b >= 0; --b) {
+    for (int b = 12; b >= 0; --b) {
         const uint32_t c = g | (1u << b);
         if (c < G && item0[c] <= it) g = c;
     }
@@ -2703,7 +2772,8 @@ __global__ __launch_bounds__(GIANT_THREADS) void giant_count_kernel(
         const uint32_t g = giant_of_item(item0, G, it);
         const uint32_t local = it - item0[g], chunk = local >> 1, half = local & 1u;
         const uint32_t bucket = glist[g], start = bstart[bucket], cnt = bstart[bucket + 1] - start;
-        const uint32_t ck = giant_chunk_of(cnt);
+        const uint32_t ck = giant_chunk_of(cnt, G);
+        const bool alone = cnt <= ck;  // the giant is one chunk: its two items store their halves of the table (no zeroing needed, no adds)
         const uint32_t c0 = chunk * ck, c1 = cnt - c0 < ck ? cnt : c0 + ck;
         {
             uint4* t4 = reinterpret_cast<uint4*>(tab);
@@ -2763,9 +2833,13 @@ __global__ __launch_bounds__(GIANT_THREADS) void giant_count_kernel(
         }
         __syncthreads();
         uint32_t* T = tables + (size_t)g * GIANT_TABLE + half * 32768u;
-        for (int i = tid; i < 32768; i += BLOCK) {
-            const uint32_t c = tab[i];
-            if (c) atomicAdd(&T[i], c);
+        if (alone) {
+            for (int i = tid; i < 32768; i += BLOCK) T[i] = tab[i];
+        } else {
+            for (int i = tid; i < 32768; i += BLOCK) {
+                const uint32_t c = tab[i];
+                if (c) atomicAdd(&T[i], c);
+            }
         }
         __syncthreads();  // the next item clears the table
     }
@@ -2812,54 +2886,67 @@ __global__ __launch_bounds__(GIANT_THREADS) void giant_scan_kernel(const Plan* _
     }
 }
 
-template <bool MAPPED>
-__global__ __launch_bounds__(GIANT_THREADS) void giant_expand_kernel(
-    uint32_t* __restrict__ buf_keys, uint32_t* __restrict__ buf_tmp, const uint32_t* __restrict__ bstart, const Plan* __restrict__ plan,
-    uint32_t neg, uint32_t pos, const uint32_t* __restrict__ glist, const uint32_t* __restrict__ gexp_item, const uint32_t* __restrict__ tables) {
-    constexpr int BLOCK = GIANT_THREADS, U = 4;
+// An expanding work item, written by giant_split_kernel (one thread per item): where its output goes, which table it
+// reads, and the values its positions span — the largest v with P[v] <= its first position and the same for its last (two
+// 16-step searches of the giant's prefixes, in L2).  A kernel of its own, after the scan: with the searches (or two probes
+// by the whole block) at the head of every expanding item the expansion ran at 1.6 TB/s, most of an item's 20 us waiting.
+struct GiantItem {
+    uint32_t dst;    // element index of the item's first output in the sorted slice
+    uint32_t o0;     // its position in the giant
+    uint32_t n_out;  // outputs (GIANT_OUT but for a giant's last item)
+    uint32_t g;      // the giant (its table)
+    uint32_t vlo, vhi;
+    uint32_t top;    // the giant's bucket index << 16
+    uint32_t pad;
+};
+static_assert(sizeof(GiantItem) == 32, "two 16-byte loads");
+
+__global__ __launch_bounds__(256) void giant_split_kernel(const Plan* __restrict__ plan, const uint32_t* __restrict__ bstart,
+                                                          const uint32_t* __restrict__ glist, const uint32_t* __restrict__ gexp_item,
+                                                          const uint32_t* __restrict__ tables, GiantItem* __restrict__ recs) {
     if (!plan->local_sort || plan->route != ROUTE_HYBRID || plan->giants == 0) return;
-    uint32_t* __restrict__ buf = plan->result_in_tmp ? buf_tmp : buf_keys;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t* s_p = reinterpret_cast<uint32_t*>(smem);                                          // [GIANT_SLICE + 1]
-    uint32_t* item0 = reinterpret_cast<uint32_t*>(smem + 4 * ((size_t)GIANT_SLICE + 1));        // [G + 1]
-    uint32_t* s_red = reinterpret_cast<uint32_t*>(smem + 4 * ((size_t)GIANT_SLICE + 1) + 4 * 1040);  // [32] wave maxima, [32..33] the two values
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t G = plan->giants, items = plan->giant_expand_items;
-    for (uint32_t i = tid; i <= G; i += BLOCK) item0[i] = gexp_item[i];
-    __syncthreads();
-    for (uint32_t it = blockIdx.x; it < items; it += gridDim.x) {
-        const uint32_t g = giant_of_item(item0, G, it);
-        const uint32_t j = it - item0[g];
+    for (uint32_t it = blockIdx.x * 256u + threadIdx.x; it < items; it += gridDim.x * 256u) {
+        const uint32_t g = giant_of_item(gexp_item, G, it);
+        const uint32_t j = it - gexp_item[g];
         const uint32_t bucket = glist[g], start = bstart[bucket], cnt = bstart[bucket + 1] - start;
         const uint32_t o0 = j * GIANT_OUT, o1 = cnt - o0 < GIANT_OUT ? cnt : o0 + GIANT_OUT;
-        const uint32_t* __restrict__ P = tables + (size_t)g * GIANT_TABLE;  // P[v] = keys below value v, P[65536] = cnt
-        // the values of positions o0 and o1 - 1: largest v with P[v] <= position.  Thread t probes P[64 t] ...
-        {
-            const uint32_t p = P[64u * (uint32_t)tid];
-            uint32_t lo = p <= o0 ? (uint32_t)tid : 0u, hi = p <= o1 - 1 ? (uint32_t)tid : 0u;  // (P[0] = 0: thread 0 always qualifies)
+        const uint32_t* __restrict__ P = tables + (size_t)g * GIANT_TABLE;
+        uint32_t a = 0, b = 0;  // P[0] = 0 <= every position
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const uint32_t a = __shfl_xor(lo, o), b = __shfl_xor(hi, o);
-                lo = a > lo ? a : lo;
-                hi = b > hi ? b : hi;
-            }
-            if (lane == 0) { s_red[wave] = lo; s_red[16 + wave] = hi; }
-            __syncthreads();
-            // ... then wave 0 / wave 1 probe the 64 values of the winning thread
-            if (wave < 2) {
-                uint32_t best = 0;
-                for (int w = 0; w < 16; ++w) best = s_red[16 * wave + w] > best ? s_red[16 * wave + w] : best;
-                const uint32_t target = wave == 0 ? o0 : o1 - 1;
-                const uint32_t v = 64u * best + (uint32_t)lane;
-                const uint64_t ok = __builtin_amdgcn_ballot_w64(P[v] <= target);  // a prefix of the lanes (P is non-decreasing), lane 0 among them
-                if (lane == 0) s_red[32 + wave] = 64u * best + (uint32_t)(63 - __builtin_clzll(ok));
-            }
-            __syncthreads();
+        for (int s = 15; s >= 0; --s) {
+            const uint32_t ca = a | (1u << s), cb = b | (1u << s);
+            if (P[ca] <= o0) a = ca;
+            if (P[cb] <= o1 - 1) b = cb;
         }
-        const uint32_t v_lo = s_red[32], v_hi = s_red[33];
-        const uint32_t top = bucket << 16;
-        for (uint32_t vs = v_lo; vs <= v_hi; vs += GIANT_SLICE) {
-            const uint32_t len = v_hi - vs + 1 < (uint32_t)GIANT_SLICE ? v_hi - vs + 1 : (uint32_t)GIANT_SLICE;  // values vs .. vs + len - 1
+        GiantItem r;
+        r.dst = start + o0; r.o0 = o0; r.n_out = o1 - o0; r.g = g; r.vlo = a; r.vhi = b; r.top = bucket << 16; r.pad = 0;
+        recs[it] = r;
+    }
+}
+
+// 256 threads and 16 KiB of LDS: eight blocks per CU, so that one item's waits (its record, its slice of the table) hide
+// behind seven others' stores.
+constexpr int GIANT_XTHREADS = 256;
+constexpr int GIANT_XSLICE = 4095;  // prefixes of a slice in LDS (plus the one behind them)
+
+template <bool MAPPED>
+__global__ __launch_bounds__(GIANT_XTHREADS, 8) void giant_expand_kernel(uint32_t* __restrict__ buf_keys, uint32_t* __restrict__ buf_tmp,
+                                                                        const Plan* __restrict__ plan, uint32_t neg, uint32_t pos,
+                                                                        const uint32_t* __restrict__ tables, const GiantItem* __restrict__ recs) {
+    constexpr int BLOCK = GIANT_XTHREADS, U = 4;
+    if (!plan->local_sort || plan->route != ROUTE_HYBRID || plan->giants == 0) return;
+    uint32_t* __restrict__ buf = plan->result_in_tmp ? buf_tmp : buf_keys;
+    __shared__ uint32_t s_p[GIANT_XSLICE + 1];
+    const int tid = threadIdx.x;
+    const uint32_t items = plan->giant_expand_items;
+    for (uint32_t it = blockIdx.x; it < items; it += gridDim.x) {
+        const GiantItem r = recs[it];  // (uniform: scalar loads)
+        const uint32_t* __restrict__ P = tables + (size_t)r.g * GIANT_TABLE;  // P[v] = keys below value v, P[65536] = the giant's length
+        const uint32_t o0 = r.o0, o1 = r.o0 + r.n_out;
+        uint32_t* __restrict__ out = buf + r.dst - r.o0;  // indexed by position in the giant
+        for (uint32_t vs = r.vlo; vs <= r.vhi; vs += GIANT_XSLICE) {
+            const uint32_t len = r.vhi - vs + 1 < (uint32_t)GIANT_XSLICE ? r.vhi - vs + 1 : (uint32_t)GIANT_XSLICE;  // values vs .. vs + len - 1
             for (uint32_t k = tid; k <= len; k += BLOCK) s_p[k] = P[vs + k];
             __syncthreads();
             const uint32_t out_lo = o0 > s_p[0] ? o0 : s_p[0], out_hi = o1 < s_p[len] ? o1 : s_p[len];
@@ -2879,8 +2966,8 @@ __global__ __launch_bounds__(GIANT_THREADS) void giant_expand_kernel(
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const uint32_t idx = base + (uint32_t)u * BLOCK + (uint32_t)tid;
-                    const uint32_t m = top | (vs + k[u]);
-                    if (idx < out_hi) buf[start + idx] = MAPPED ? unmap_key<uint32_t>(m, neg, pos) : m;
+                    const uint32_t m = r.top | (vs + k[u]);
+                    if (idx < out_hi) out[idx] = MAPPED ? unmap_key<uint32_t>(m, neg, pos) : m;
                 }
             }
             __syncthreads();  // the next slice / item overwrites s_p
@@ -3483,14 +3570,23 @@ struct DeviceState {
 };
 DeviceState g_dev[16];
 
-constexpr int MSD_WAVES = 12;
-constexpr int msd_kpt(size_t key_bytes) { return key_bytes == 4 ? 22 : 11; }  // ROUTE_ATOMIC tiles: 66 KiB of keys, two blocks per CU
+#ifndef RDST_MSD_WAVES
+#define RDST_MSD_WAVES 12
+#endif
+#ifndef RDST_MSD_KPT4
+#define RDST_MSD_KPT4 22
+#endif
+#ifndef RDST_MSD_KPT8
+#define RDST_MSD_KPT8 11
+#endif
+constexpr int MSD_WAVES = RDST_MSD_WAVES;
+constexpr int msd_kpt(size_t key_bytes) { return key_bytes == 4 ? RDST_MSD_KPT4 : RDST_MSD_KPT8; }  // ROUTE_ATOMIC tiles: 66 KiB of keys, two blocks per CU
 
 struct Layout {
     uint32_t levels, tile, status_bytes;  // status_bytes: 4 or 8 per word
     uint64_t tiles;
     size_t off_err, off_tickets, off_plan, off_hpos, off_hpair, off_h16, off_hpos16, off_status, off_status_near, zero_bytes, off_hist, off_base,
-        off_cbase, off_chains, off_bstart, off_fblist, off_fblist2, off_glist, off_gtables, off_halves, off_cursor_a, off_cursor_b, off_msd_a, total;
+        off_cbase, off_chains, off_bstart, off_fblist, off_fblist2, off_glist, off_gsplit, off_gtables, off_halves, off_cursor_a, off_cursor_b, off_msd_a, total;
     uint32_t msd_cap_a, msd_slices;  // ROUTE_ATOMIC: keys an area of pass A holds; areas per top digit
     uint32_t slot_cap;               // and keys a bucket's slot (pass B's destination) holds
 };
@@ -3502,7 +3598,10 @@ int tile_keys(int cfg, uint32_t elem_bytes) {
     return p.nwaves * 64 * kpt_for(p.kpt8, elem_bytes);
 }
 
-constexpr uint32_t GIANT_MAX = 1024;  // count tables of the hybrid route's giant buckets (256 KiB each)
+// count tables of the hybrid route's giant buckets (256 KiB each: 1 GiB, in the atomic route's areas when it has them) —
+// 10^9 normally distributed f32 keys make ~1 800 giants
+constexpr uint32_t GIANT_MAX = 4096;
+static_assert(GIANT_MAX + 1 <= GIANT_ITEMS_LDS, "the giant kernels keep every giant's first work item in LDS");
 
 Layout make_layout(uint64_t n, uint32_t elem_bytes, uint32_t levels, int cfg, uint32_t tile_override = 0, bool want_halves = false,
                    bool want_msd = false, bool want_giants = false) {
@@ -3535,6 +3634,9 @@ Layout make_layout(uint64_t n, uint32_t elem_bytes, uint32_t levels, int cfg, ui
     L.off_fblist = o; o += sizeof(uint32_t) * (size_t)H16_BINS;           // buckets the first K4 kernel hands on (count: header word 3)
     L.off_fblist2 = o; o += sizeof(uint32_t) * (size_t)H16_BINS;          // and those the second one hands on (count: header word 5)
     L.off_glist = o; o += sizeof(uint32_t) * 3 * ((size_t)GIANT_MAX + 16); // giants of the hybrid route: buckets, first counting item, first expanding item
+    o = align_up(o, 32);
+    L.off_gsplit = o;
+    if (want_giants) o += sizeof(GiantItem) * (size_t)(n / GIANT_OUT + GIANT_MAX + 16);
     o = align_up(o, 256);
     L.off_halves = o;                                                       // hybrid route, 4-byte keys: low halves between pass L-1 and K4
     if (want_halves && !want_msd) o += align_up(sizeof(uint16_t) * n, 256);
@@ -3768,6 +3870,7 @@ constexpr int COUNT_THREADS = RDST_COUNT_THREADS;
 // over the (normally empty) list of buckets it could not take; 8-byte keys: the generic one over all buckets.
 struct GiantArgs {
     uint32_t *glist, *gcount_item, *gexp_item, *tables;
+    GiantItem* recs;
 };
 
 template <typename K>
@@ -3816,7 +3919,7 @@ int launch_local_sort(K* keys, K* tmp, const uint32_t* bstart, const Plan* plan,
 #undef RDST_EXPAND
                 HIP_TRY(hipGetLastError());
                 if (ga) {  // the giants of the hybrid route (route_kernel listed them; none: four launches that return at once)
-                    constexpr size_t clds2 = giant_count_lds_bytes(), xlds = giant_expand_lds_bytes();
+                    constexpr size_t clds2 = giant_count_lds_bytes();
                     hipLaunchKernelGGL(giant_zero_kernel, dim3((uint32_t)cus * 4), dim3(256), 0, s, plan, ga->tables);
 #define RDST_GCOUNT(MAPPED, FROM16)                                                                                                  \
     do {                                                                                                                             \
@@ -3828,15 +3931,9 @@ int launch_local_sort(K* keys, K* tmp, const uint32_t* bstart, const Plan* plan,
                     else { if (mapped) RDST_GCOUNT(true, false); else RDST_GCOUNT(false, false); }
 #undef RDST_GCOUNT
                     hipLaunchKernelGGL(giant_scan_kernel, dim3((uint32_t)cus), dim3(GIANT_THREADS), 0, s, plan, ga->tables);
-                    if (mapped) {
-                        if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&giant_expand_kernel<true>), xlds)) return rc;
-                        hipLaunchKernelGGL((giant_expand_kernel<true>), dim3((uint32_t)cus * 2), dim3(GIANT_THREADS), xlds, s, keys, tmp, bstart, plan,
-                                           (uint32_t)km.neg, (uint32_t)km.pos, ga->glist, ga->gexp_item, ga->tables);
-                    } else {
-                        if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&giant_expand_kernel<false>), xlds)) return rc;
-                        hipLaunchKernelGGL((giant_expand_kernel<false>), dim3((uint32_t)cus * 2), dim3(GIANT_THREADS), xlds, s, keys, tmp, bstart, plan,
-                                           (uint32_t)km.neg, (uint32_t)km.pos, ga->glist, ga->gexp_item, ga->tables);
-                    }
+                    hipLaunchKernelGGL(giant_split_kernel, dim3((uint32_t)cus * 2), dim3(256), 0, s, plan, bstart, ga->glist, ga->gexp_item, ga->tables, ga->recs);
+                    if (mapped) hipLaunchKernelGGL((giant_expand_kernel<true>), dim3((uint32_t)cus * 8), dim3(GIANT_XTHREADS), 0, s, keys, tmp, plan, (uint32_t)km.neg, (uint32_t)km.pos, ga->tables, ga->recs);
+                    else hipLaunchKernelGGL((giant_expand_kernel<false>), dim3((uint32_t)cus * 8), dim3(GIANT_XTHREADS), 0, s, keys, tmp, plan, (uint32_t)km.neg, (uint32_t)km.pos, ga->tables, ga->recs);
                     HIP_TRY(hipGetLastError());
                 }
                 return RDST_OK;  // (the list is spent: nothing is left for the ranked kernel)
@@ -4093,7 +4190,7 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
         if (try_atomic) {
             constexpr int KPT = msd_kpt(sizeof(K)), NW = MSD_WAVES, TILE = NW * 64 * KPT, W = (int)sizeof(K) * 8;
             constexpr bool HALF = sizeof(K) == 4;  // 4-byte keys leave pass B as their low halves
-            constexpr size_t mlds = (size_t)NW * 1024 + 1024 + 64 + sizeof(K) * TILE;
+            constexpr size_t mlds = (size_t)NW * 1024 + 1024 + 128 + sizeof(K) * TILE;
             const uint32_t slot_cap = L.slot_cap;
             uint32_t* overflow = reinterpret_cast<uint32_t*>(ws + L.off_err) + 4;
             uint32_t* cursor_a = reinterpret_cast<uint32_t*>(ws + L.off_cursor_a);
@@ -4229,6 +4326,7 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
             ga.gcount_item = ga.glist + GIANT_MAX + 16;
             ga.gexp_item = ga.gcount_item + GIANT_MAX + 16;
             ga.tables = reinterpret_cast<uint32_t*>(ws + L.off_gtables);
+            ga.recs = reinterpret_cast<GiantItem*>(ws + L.off_gsplit);
             rc = launch_local_sort<K>(keys, tmp, reinterpret_cast<const uint32_t*>(ws + L.off_bstart), plan, D->err_dev, km,
                                       reinterpret_cast<uint32_t*>(ws + L.off_fblist), reinterpret_cast<uint32_t*>(ws + L.off_err) + 3,
                                       from16 ? reinterpret_cast<const uint16_t*>(ws + L.off_halves) : nullptr, D->cus, s,

@@ -126,3 +126,20 @@ def test_skewed_full_size_inputs(gpu):
                 assert _is_sorted(torch, keys ^ torch.iinfo(torch.int32).min), (mode, name)
         finally:
             gpu.set_hybrid(True)
+
+
+def test_more_giants_than_tables_take_the_lsd_route(gpu):
+    """8 192 prefixes of ~73 000 keys each: twice the count tables the hybrid route's giant kernels have."""
+    import torch
+    n = 600_000_000
+    keys = (torch.arange(n, dtype=torch.int64, device="cuda") * 2654435761) & 0x1FFFFFFF
+    keys = keys.to(torch.int32)
+    src_sum, src_x = int(keys.sum()), int((keys ^ (keys >> 11)).sum())
+    gpu.set_hybrid(True, 1)
+    try:
+        gpu.sort_device_tensor(keys.view(torch.uint32))
+        assert gpu.last_route() == "lsd"
+    finally:
+        gpu.set_hybrid(True)
+    assert int(keys.sum()) == src_sum and int((keys ^ (keys >> 11)).sum()) == src_x
+    assert _is_sorted(torch, keys)   # (all below 2^29: the signed order is the unsigned one)
