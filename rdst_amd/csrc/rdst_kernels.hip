@@ -109,9 +109,20 @@ struct Plan {
     uint32_t gross_skew;              // a sample of the keys already rules the hybrid route out (presample_kernel): K1h returns at once
     uint32_t top_skew;                // the sample's top bytes are far from uniform: the atomic route's areas would overflow, its passes return at once
     uint32_t giants, giant_count_items, giant_expand_items;  // hybrid route, 4-byte keys: buckets of 65 536 keys and more and the work items of their kernels (route_kernel)
+    // ROUTE_ATOMIC's bucket window: the sample's keys share their top win_shift bits (value win_top) — keys below 2^30, one
+    // rank's share of a sharded sort — so the 16 bits that make the 65 536 buckets start win_shift bits lower (pass A checks
+    // every key against win_top; one that differs gives the route up)
+    uint32_t win_shift, win_top;
     uint32_t low_dups;                // (4-byte keys) the sample's low halves repeat: K4's first kernel (4-bit counters) would refuse most buckets, it hands them all on
     uint32_t sorted_known;            // K1h swept the whole slice and met no inversion: K1 need not read it again (K2 turns every pass off)
 };
+
+// top 16 bits (of the mapped key) of the keys of bucket b: b itself, or — atomic route with a lowered window — the shared top
+// bits followed by the bucket's upper ones (its lowest win_shift bits lie below bit W - 16: they are part of what K4 sorts)
+__device__ __forceinline__ uint32_t bucket_prefix16(const Plan* plan, uint32_t bucket) {
+    const uint32_t sh = plan->route == 2u /* ROUTE_ATOMIC */ ? plan->win_shift : 0u;
+    return (((plan->win_top << 16) | bucket) >> sh) & 0xFFFFu;
+}
 
 // Look-back chains.  One chain over all tiles makes every tile walk back over ~(status latency /
 // tile start interval) predecessor rows, and those re-reads are fabric traffic on the scale of
@@ -425,7 +436,7 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const K* __restrict_
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t PRESAMPLE_KEYS = 8192;  // 65 536 spread-out keys cost 0.17 ms (a TLB miss each); 8 192 in one batch of loads: ~0.01 ms
 constexpr uint64_t PRESAMPLE_MIN_LEN = 1ull << 28;  // below it a full tile expects more hits than 8-bit counters and a small limit allow
-constexpr size_t presample_lds_bytes() { return 2 * H16_BINS + 16 + 4 * RADIX; }
+constexpr size_t presample_lds_bytes() { return 2 * H16_BINS + 32 + 4 * RADIX; }
 // low halves of the sample that were seen before: S - D (1 - exp(-S / D)) for S = 8 192 samples over D equally likely values:
 // ~490 on uniform keys (D = 65 536), 3 000 for D = 8 192, 5 000 for D ~ 3 500 — where a bucket of 15 000 keys holds each value
 // 4-5 times on average and one of them 16 times often enough that K4's first kernel refuses a good part of the buckets
@@ -437,14 +448,13 @@ __global__ __launch_bounds__(1024) void presample_kernel(const K* __restrict__ k
     constexpr int W = sizeof(K) * 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* s_c = reinterpret_cast<uint32_t*>(smem);               // 65 536 8-bit counters, four per word
-    uint32_t* s_skew = reinterpret_cast<uint32_t*>(smem + H16_BINS);   // [0] a prefix over the limit, [1] a top byte over its limit, [2] repeated low halves
-    uint32_t* s_top = reinterpret_cast<uint32_t*>(smem + H16_BINS + 16); // [256] the sample's top bytes
-    uint32_t* s_low = reinterpret_cast<uint32_t*>(smem + H16_BINS + 16 + 4 * RADIX);  // 65 536 8-bit counters of the low halves (4-byte keys)
+    uint32_t* s_skew = reinterpret_cast<uint32_t*>(smem + H16_BINS);   // [0] a prefix over the limit, [1] a top byte over its limit, [2] repeated low halves, [4] / [5] AND / OR of the top 16 bits
+    uint32_t* s_top = reinterpret_cast<uint32_t*>(smem + H16_BINS + 32); // [256] the sample's top bytes
+    uint32_t* s_low = reinterpret_cast<uint32_t*>(smem + H16_BINS + 32 + 4 * RADIX);  // 65 536 8-bit counters of the low halves (4-byte keys)
     const int tid = threadIdx.x;
     for (int i = tid; i < H16_BINS / 4; i += 1024) { s_c[i] = 0; s_low[i] = 0; }
     if (tid < RADIX) s_top[tid] = 0;
     if (tid < 4) s_skew[tid] = 0;
-    __syncthreads();
     const uint64_t step = n / PRESAMPLE_KEYS;
     bool skew = false;
     static_assert(PRESAMPLE_KEYS == 8 * 1024, "eight keys per thread, one batch");
@@ -452,10 +462,31 @@ __global__ __launch_bounds__(1024) void presample_kernel(const K* __restrict__ k
     {
 #pragma unroll
         for (int u = 0; u < 8; ++u) v[u] = keys[((uint64_t)u * 1024 + tid) * step];
+        // the window: how many of their top 8 bits do the samples share?
+        if (tid == 0) { s_skew[4] = 0xFFFFu; s_skew[5] = 0; }
+        __syncthreads();
+        uint32_t band = 0xFFFFu, bor = 0;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const K m = MAPPED ? map_key<K>(v[u], neg, pos) : v[u];
-            const uint32_t b = (uint32_t)(m >> (W - 16));
+            v[u] = MAPPED ? map_key<K>(v[u], neg, pos) : v[u];
+            band &= (uint32_t)(v[u] >> (W - 16));
+            bor |= (uint32_t)(v[u] >> (W - 16));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            band &= __shfl_xor(band, o);
+            bor |= __shfl_xor(bor, o);
+        }
+        if ((tid & 63) == 0) { atomicAnd(&s_skew[4], band); atomicOr(&s_skew[5], bor); }
+        __syncthreads();
+        const uint32_t diff = (s_skew[4] ^ s_skew[5]) & 0xFFFFu;
+        const uint32_t lead = diff ? (uint32_t)__builtin_clz(diff) - 16u : 16u;
+        const uint32_t ws = lead < 8u ? lead : 8u;  // at most a byte: the buckets stay 16 bits of the key
+        if (tid == 0) { plan->win_shift = ws; plan->win_top = ws ? s_skew[5] >> (16u - ws) : 0u; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const K m = v[u];
+            const uint32_t b = (uint32_t)(m >> (W - 16 - (int)ws)) & 0xFFFFu;  // the bucket the atomic route would put the key in
             const uint32_t sh = (b & 3u) * 8u;
             const uint32_t old = atomicAdd(&s_c[b >> 2], 1u << sh);
             skew |= ((old >> sh) & 0xFFu) + 1u >= limit;  // limit <= 64: the flag fires long before a counter could carry
@@ -1716,6 +1747,8 @@ __global__ __launch_bounds__(NWAVES * 64, RDST_MSD_MINWAVES) void msd_scatter_ke
     // the sample or an earlier tile already gave the route up (a coherent load: the flag is raised by blocks on other XCDs)
     if (plan->gross_skew || plan->top_skew || ld_relaxed<uint32_t>(overflow)) return;
     if (SECOND && *inversion == 0) return;      // pass A met no inversion: the slice is sorted, nothing to do
+    const int win = (int)plan->win_shift;       // the buckets' 16 bits start this far below the key's top (presample_kernel)
+    shift -= win;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* wave_hist = reinterpret_cast<uint32_t*>(smem);                           // [NWAVES][256]
     uint32_t* s_delta = reinterpret_cast<uint32_t*>(smem + NWAVES * 1024);             // [256] destination of tile slot 0 of a digit's run (elements, mod 2^32)
@@ -1769,6 +1802,14 @@ __global__ __launch_bounds__(NWAVES * 64, RDST_MSD_MINWAVES) void msd_scatter_ke
         }
         // (one word for the whole grid: look before setting — 700 000 waves OR-ing the same word took 8 ms, ~88 atomics per us)
         if (__builtin_amdgcn_ballot_w64(inv) != 0 && lane == 0 && ld_relaxed<uint32_t>(inversion) == 0) atomicOr(inversion, 1u);
+        if (win) {  // every key must carry the top bits the sample's keys share: one that does not gives the route up
+            constexpr int KW = (int)sizeof(K) * 8;
+            const K want = (K)plan->win_top;
+            bool stray = false;
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) stray |= (full || wbase + i * 64 < valid) && (K)(mk[i] >> (KW - win)) != want;
+            if (__builtin_amdgcn_ballot_w64(stray) != 0 && lane == 0 && ld_relaxed<uint32_t>(overflow) == 0) atomicOr(overflow, 1u);
+        }
     }
     __builtin_amdgcn_s_setprio(0);
     uint32_t* wh = wave_hist + wave * RADIX;
@@ -2036,7 +2077,8 @@ constexpr size_t local_lds_bytes(size_t key_bytes) { return (size_t)local_waves(
 template <typename K, int NWAVES, int KPT, bool MAPPED>
 __device__ __forceinline__ void local_sort_bucket(K* __restrict__ buf, const uint16_t* __restrict__ src16 /* nullable: low halves of the mapped keys */,
                                                   const K* __restrict__ alt_src /* nullable: whole (raw) keys lie here, not at their final place */,
-                                                  const uint32_t soff /* where the bucket lies in src16 / alt_src */, const uint32_t bucket, const uint32_t start, const uint32_t cnt,
+                                                  const uint32_t soff /* where the bucket lies in src16 / alt_src */, const uint32_t bucket,
+                                                  const uint32_t top16 /* top 16 bits of the bucket's (mapped) keys: bucket_prefix16 */, const uint32_t start, const uint32_t cnt,
                                                   uint32_t* __restrict__ err, K neg, K pos, uint32_t flags) {
     constexpr int BLOCK = NWAVES * 64, TILE = BLOCK * KPT, W = sizeof(K) * 8, LOCAL = (int)sizeof(K) - 2;
     constexpr uint32_t SLOT_UNIT = (uint32_t)sizeof(K);  // running slots count in bytes of the staging buffer
@@ -2044,7 +2086,7 @@ __device__ __forceinline__ void local_sort_bucket(K* __restrict__ buf, const uin
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (cnt <= 1) {
         if (sizeof(K) == 4 && src16 && cnt == 1 && tid == 0) {  // the key exists only as its low half
-            const K m = (K)((K)bucket << (W - 16)) | (K)src16[soff];
+            const K m = (K)((K)top16 << (W - 16)) | (K)src16[soff];
             buf[start] = MAPPED ? unmap_key<K>(m, neg, pos) : m;
         }
         if (alt_src && cnt == 1 && tid == 0) buf[start] = alt_src[soff];
@@ -2062,7 +2104,7 @@ __device__ __forceinline__ void local_sort_bucket(K* __restrict__ buf, const uin
     const int rounds = (int)((cnt + BLOCK - 1) / BLOCK);
     const uint32_t live = (uint32_t)rounds * BLOCK;
     const uint32_t wbase = (uint32_t)wave * 64u * (uint32_t)rounds + (uint32_t)lane;
-    const K sentinel = (K)((K)bucket << (W - 16)) | (K)(((K)1 << (W - 16)) - 1);
+    const K sentinel = (K)((K)top16 << (W - 16)) | (K)(((K)1 << (W - 16)) - 1);
 
     __builtin_amdgcn_s_setprio(RDST_PRIO_LOAD);
     K mk[KPT];
@@ -2075,7 +2117,7 @@ __device__ __forceinline__ void local_sort_bucket(K* __restrict__ buf, const uin
                 const uint32_t idx = wbase + i * 64;
                 const uint32_t at = idx < cnt ? idx : cnt - 1;
                 if (sizeof(K) == 4 && src16) {  // block-uniform
-                    if (idx < cnt) v = (K)((K)bucket << (W - 16)) | (K)src16[soff + at];
+                    if (idx < cnt) v = (K)((K)top16 << (W - 16)) | (K)src16[soff + at];
                 } else {
                     const K raw = tsrc[at];
                     if (idx < cnt) v = MAPPED ? map_key<K>(raw, neg, pos) : raw;
@@ -2255,7 +2297,7 @@ __global__ __launch_bounds__(NWAVES * 64, (sizeof(K) <= 4 ? 2 : 1) * NWAVES / 4)
     if (list == nullptr) {
         const uint32_t bucket = blockIdx.x;
         const uint32_t start = bstart[bucket];
-        local_sort_bucket<K, NWAVES, KPT, MAPPED>(buf, src16, nullptr, start, bucket, start, bstart[bucket + 1] - start, err, neg, pos, flags);
+        local_sort_bucket<K, NWAVES, KPT, MAPPED>(buf, src16, nullptr, start, bucket, bucket_prefix16(plan, bucket), start, bstart[bucket + 1] - start, err, neg, pos, flags);
         return;
     }
     const uint32_t todo = *list_count;
@@ -2264,7 +2306,7 @@ __global__ __launch_bounds__(NWAVES * 64, (sizeof(K) <= 4 ? 2 : 1) * NWAVES / 4)
         const uint32_t bucket = list[e];
         const uint32_t start = bstart[bucket];
         const uint32_t cnt = slot_count ? slot_count[bucket] : bstart[bucket + 1] - start;
-        local_sort_bucket<K, NWAVES, KPT, MAPPED>(buf, src16, alt_src, slot_count ? bucket * slot_cap : start, bucket, start, cnt, err, neg, pos, flags);
+        local_sort_bucket<K, NWAVES, KPT, MAPPED>(buf, src16, alt_src, slot_count ? bucket * slot_cap : start, bucket, bucket_prefix16(plan, bucket), start, cnt, err, neg, pos, flags);
         __syncthreads();  // the next bucket reuses the LDS
     }
 }
@@ -2313,7 +2355,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 8 : 6) void local_count_sort
     if (cnt <= 1) {
         if constexpr (FROM16) {  // the key exists only as its low half: put it back together
             if (cnt == 1 && tid == 0) {
-                const uint32_t m = (bucket << 16) | (uint32_t)src16[soff];
+                const uint32_t m = (bucket_prefix16(plan, bucket) << 16) | (uint32_t)src16[soff];
                 buf[start] = MAPPED ? unmap_key<uint32_t>(m, neg, pos) : m;
             }
         }
@@ -2372,7 +2414,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 8 : 6) void local_count_sort
         const int any = __syncthreads_or((int)differ);       // every wave of one value ...
         const bool agree = first == s_wsum[17] || (uint32_t)(tid & ~63) >= cnt;
         if (!any && !__syncthreads_or((int)!agree)) {       // ... and the same one
-            const uint32_t m = (bucket << 16) | first;
+            const uint32_t m = (bucket_prefix16(plan, bucket) << 16) | first;
             const uint32_t out = MAPPED ? unmap_key<uint32_t>(m, neg, pos) : m;
 #pragma unroll
             for (int i = 0; i < MAXR; ++i) {
@@ -2429,7 +2471,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 8 : 6) void local_count_sort
     __syncthreads();
     __builtin_amdgcn_s_setprio(RDST_PRIO_SCATTER);
     uint32_t* tdst = buf + start;
-    const uint32_t top = bucket << 16;
+    const uint32_t top = bucket_prefix16(plan, bucket) << 16;
 #pragma unroll
     for (int i = 0; i < MAXR; ++i) {
         const uint32_t idx = (uint32_t)tid + i * BLOCK;
@@ -2537,7 +2579,7 @@ __global__ __launch_bounds__(EXPAND_THREADS) void local_expand_sort_kernel(
             }
         }
         __syncthreads();
-        const uint32_t top = bucket << 16;
+        const uint32_t top = bucket_prefix16(plan, bucket) << 16;
         for (uint32_t base = 0; base < cnt; base += BLOCK * U) {
             uint32_t v[U];
 #pragma unroll
@@ -2628,7 +2670,7 @@ __global__ __launch_bounds__(COUNT16_THREADS) void local_count16_sort_kernel(
             for (int i = 0; i < KPT; ++i) differ |= kv[i] != first;  // (slots past cnt repeat the last key)
             if (!__syncthreads_or((int)differ)) {
                 if constexpr (FROM16) {
-                    const uint32_t m = (bucket << 16) | first;
+                    const uint32_t m = (bucket_prefix16(plan, bucket) << 16) | first;
                     const uint32_t out = MAPPED ? unmap_key<uint32_t>(m, neg, pos) : m;
 #pragma unroll
                     for (int i = 0; i < KPT; ++i) {
@@ -2705,7 +2747,7 @@ __global__ __launch_bounds__(COUNT16_THREADS) void local_count16_sort_kernel(
         }
         __syncthreads();
         uint32_t* tdst = buf + start;
-        const uint32_t top = bucket << 16;
+        const uint32_t top = bucket_prefix16(plan, bucket) << 16;
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
             const uint32_t idx = (uint32_t)tid + i * BLOCK;
@@ -3116,7 +3158,7 @@ __global__ __launch_bounds__(WIDE_THREADS, 4) void local_wide_sort_kernel(
         for (int i = 0; i < MAXR; ++i) {
             const uint32_t idx = (uint32_t)tid + i * BLOCK;
             const uint32_t rel = (uint32_t)(mk[i] >> 48) - (uint32_t)(h * HALF);
-            if (idx < cnt && rel < (uint32_t)HALF) out64[rel] = (mk[i] & LOW48) | ((uint64_t)bucket << 48);
+            if (idx < cnt && rel < (uint32_t)HALF) out64[rel] = (mk[i] & LOW48) | ((uint64_t)bucket_prefix16(plan, bucket) << 48);
         }
         __syncthreads();
         __builtin_amdgcn_s_setprio(RDST_PRIO_SCATTER);
@@ -3281,7 +3323,7 @@ __global__ __launch_bounds__(WIDE2_THREADS, 8) void local_wide2_sort_kernel(
         for (int i = 0; i < MAXR; ++i) {
             const uint32_t idx = (uint32_t)tid + i * BLOCK;
             const uint32_t rel = (uint32_t)(mk[i] >> 48) - (uint32_t)(h * HALF);
-            if (idx < cnt && rel < (uint32_t)HALF) out64[rel] = (mk[i] & LOW48) | ((uint64_t)bucket << 48);
+            if (idx < cnt && rel < (uint32_t)HALF) out64[rel] = (mk[i] & LOW48) | ((uint64_t)bucket_prefix16(plan, bucket) << 48);
         }
         __syncthreads();
         __builtin_amdgcn_s_setprio(RDST_PRIO_SCATTER);

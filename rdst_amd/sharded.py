@@ -81,28 +81,29 @@ class HipEngine:
 
 
 def split_digits(global_counts: Sequence[int], world: int) -> List[int]:
-    """Owner rank of each bucket (256 top digits, or 65 536 prefixes): contiguous ranges, each closed as soon as
-    its running total reaches the ideal prefix (r+1)*N/world.  Deterministic, same on every rank.  Host form of
-    `_owners` below (kept for the tests and as the definition)."""
+    """Owner rank of each bucket (256 top digits, or 65 536 prefixes): contiguous ranges; a bucket goes to the rank whose
+    ideal range [r*N/world, (r+1)*N/world) holds its MIDDLE key.  Deterministic, same on every rank.  Host form of `_owners`
+    below (kept for the tests and as the definition).  (The middle, not the first key: on uniform keys the ranges then end
+    exactly on multiples of 256/world digits — every rank's keys share their top log2(world) bits, which the local sort's
+    atomic route turns into a lowered bucket window — where "first key" hands rank r one digit of rank r+1's every time a
+    running total falls a hair short.)"""
     total = int(sum(int(c) for c in global_counts))
     owner = [0] * len(global_counts)
-    r, run = 0, 0
+    below = 0
     for d in range(len(global_counts)):
-        owner[d] = r
-        run += int(global_counts[d])
-        while r < world - 1 and run * world >= (r + 1) * total and total > 0:
-            r += 1
+        c = int(global_counts[d])
+        owner[d] = min(world - 1, (world * (2 * below + c)) // (2 * total)) if total > 0 else 0
+        below += c
     return owner
 
 
 def _owners(table, world):
-    """split_digits on the device: owner[d] = min(world-1, floor(world * (keys below d) / total)) — the number of
-    ideal prefixes k*N/world (k >= 1) that the buckets before d have reached."""
+    """split_digits on the device: owner[d] = min(world-1, floor(world * (keys below d + half of d's) / total))."""
     import torch
     glob = table.sum(dim=0)
     total = glob.sum()
     below = torch.cumsum(glob, dim=0) - glob
-    owner = torch.div(below * world, torch.clamp(total, min=1), rounding_mode="floor")
+    owner = torch.div((2 * below + glob) * world, torch.clamp(2 * total, min=1), rounding_mode="floor")
     return torch.clamp(owner, max=world - 1)
 
 

@@ -129,17 +129,43 @@ def test_skewed_full_size_inputs(gpu):
 
 
 def test_more_giants_than_tables_take_the_lsd_route(gpu):
-    """8 192 prefixes of ~73 000 keys each: twice the count tables the hybrid route's giant kernels have."""
+    """every eighth 16-bit prefix holds ~73 000 keys: 8 192 giants, twice the count tables the hybrid route's giant kernels
+    have (pass B of the atomic route overflows its slots first; the top bytes alone look uniform)."""
     import torch
     n = 600_000_000
-    keys = (torch.arange(n, dtype=torch.int64, device="cuda") * 2654435761) & 0x1FFFFFFF
-    keys = keys.to(torch.int32)
+    i = torch.arange(n, dtype=torch.int64, device="cuda")
+    keys = ((((i * 2654435761) & 0x1FFF) * 8 + 3) << 16) | ((i * 40503) & 0xFFFF)
+    keys = keys.to(torch.int32)          # (wraps: the bits are what counts)
+    del i
     src_sum, src_x = int(keys.sum()), int((keys ^ (keys >> 11)).sum())
-    gpu.set_hybrid(True, 1)
-    try:
-        gpu.sort_device_tensor(keys.view(torch.uint32))
-        assert gpu.last_route() == "lsd"
-    finally:
-        gpu.set_hybrid(True)
+    gpu.sort_device_tensor(keys.view(torch.uint32))
+    assert gpu.last_route() == "lsd"
     assert int(keys.sum()) == src_sum and int((keys ^ (keys >> 11)).sum()) == src_x
-    assert _is_sorted(torch, keys)   # (all below 2^29: the signed order is the unsigned one)
+    assert _is_sorted(torch, _mapped(torch, keys, "u"))
+
+
+def test_keys_that_share_their_top_bits_take_the_atomic_route_through_a_lowered_window(gpu):
+    """Keys below 2^30 (ids), one rank's share of an 8-way sharded sort (top byte in [32, 64)), positive i32, f32 in [0.5, 2):
+    the sample's keys share their top 2 / 3 / 1 / 8 bits, the atomic route's 65 536 buckets are taken that many bits lower
+    and the slice sorts as fast as uniform keys do.  One stray key the sample does not see is caught by pass A's check of
+    every key (the route is given up, the next one sorts)."""
+    import torch
+    n = 400_000_000
+    g = torch.Generator(device="cuda").manual_seed(0x5D57000A)
+    r = torch.randint(-(2**31), 2**31, (n,), dtype=torch.int32, device="cuda", generator=g)
+    cases = [("uint32", r & 0x3FFFFFFF, "atomic"),
+             ("uint32", (r & 0x1FFFFFFF) | 0x20000000, "atomic"),
+             ("int32", r & 0x7FFFFFFF, "atomic"),
+             ("float32", (r & 0x00FFFFFF) | 0x3F000000, "atomic")]   # f32 in [0.5, 2): sign and seven exponent bits shared
+    stray = (r & 0x3FFFFFFF).clone()
+    stray[123_456_789] = -1                      # 0xFFFFFFFF (no sampled position: they are multiples of n / 8192)
+    cases.append(("uint32", stray, None))
+    for name, src, want in cases:
+        keys = src.clone()
+        s1, s2 = int(keys.sum()), int((keys ^ (keys >> 11)).sum())
+        gpu.sort_device_tensor(keys.view(getattr(torch, name)))
+        route = gpu.last_route()
+        assert (route == want) if want else (route != "atomic"), (name, route)
+        assert int(keys.sum()) == s1 and int((keys ^ (keys >> 11)).sum()) == s2, name
+        assert _is_sorted(torch, _mapped(torch, keys, np.dtype(name).kind)), name
+        del keys

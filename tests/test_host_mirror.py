@@ -64,8 +64,10 @@ def test_split_digits_balances_and_is_contiguous():
         for counts in ([1000] * 256, rng.integers(0, 5000, size=256).tolist(), [0] * 255 + [10**6], [10**6] + [0] * 255,
                        [0] * 256):
             owner = split_digits(counts, world)
-            assert len(owner) == 256 and owner[0] == 0 and all(0 <= o < world for o in owner)
+            assert len(owner) == 256 and all(0 <= o < world for o in owner)   # (a bucket goes where its middle key falls: one bucket holding everything is the middle rank's)
             assert all(b - a in (0, 1) or b > a for a, b in zip(owner, owner[1:])) and owner == sorted(owner)
+            if counts == [1000] * 256 and 256 % world == 0:   # uniform keys: ranges end on multiples of 256 / world digits
+                assert all(owner[d] == d // (256 // world) for d in range(256))
             if counts == [1000] * 256:
                 per = [sum(c for c, o in zip(counts, owner) if o == r) for r in range(world)]
                 assert max(per) - min(per) <= 1000 * (256 % world != 0) + 1000

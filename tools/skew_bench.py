@@ -23,6 +23,8 @@ cases = {
     "byte 1 in two digits": rnd & ~0xFE00,
     "byte 1 constant (skipped level)": (rnd & ~0xFF00) | 0x4200,
     "gaussian-ish (sum of 4 uniforms)": ((rnd >> 2) + (torch.roll(rnd, 1) >> 2) + (torch.roll(rnd, 2) >> 2) + (torch.roll(rnd, 3) >> 2)),
+    "ids below 2^30 (top 2 bits shared)": rnd & 0x3FFFFFFF,
+    "one rank's share of 8 (top byte in [32, 64))": (rnd & 0x1FFFFFFF) | 0x20000000,
     "f32 normal(0, 1) [sorted as f32]": torch.randn(n, dtype=torch.float32, device="cuda", generator=g).view(torch.int32),
     "f32 uniform [0, 1) [sorted as f32]": torch.rand(n, dtype=torch.float32, device="cuda", generator=g).view(torch.int32),
 }

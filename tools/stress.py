@@ -31,6 +31,21 @@ def gen(n, it, kind):
     elif kind == 5: r = r & ~0xFF00 | 0x4200 if bits >= 16 else r   # level 1 constant
     elif kind == 6: r = r.sort().values                             # sorted as integers
     elif kind == 7: r &= 0x0F0F0F0F if bits == 32 else r            # 16 values per digit
+    elif kind == 8 and bits >= 32:                                    # a few 16-bit prefixes hold everything (giant buckets)
+        k = int(torch.randint(1, 200, (1,)))
+        pref = torch.randint(0, 1 << 16, (k,), dtype=torch.int64, device="cuda", generator=g)
+        pick = pref[torch.randint(0, k, (n,), device="cuda", generator=g)]
+        low = r.to(torch.int64) & ((1 << (bits - 16)) - 1)
+        r = ((pick << (bits - 16)) | low).to(it)
+    elif kind == 9 and bits == 32:                                    # a float column (sorted as whatever the type is)
+        r = (torch.randn(n, dtype=torch.float32, device="cuda", generator=g) * float(10 ** (torch.rand(1) * 6 - 3))).view(torch.int32)
+    elif kind == 10: r = torch.full_like(r, int(r[0]))               # one value
+    elif kind == 11: r = torch.where(r > 0, r[:1], r[-1:])            # two values
+    elif kind == 12 and bits >= 32:                                   # dense ids, shuffled
+        r = torch.randperm(n, device="cuda", generator=g).to(it) + int(torch.randint(0, 1 << 20, (1,)))
+    elif kind == 13 and bits >= 32:                                   # bimodal (gen_inputs with shift = half the width)
+        h = bits // 2
+        r = torch.cat([(r[: n // 2] >> h) & ((1 << h) - 1), r[n // 2:] << h])
     return r.contiguous()
 
 
@@ -40,7 +55,10 @@ while time.time() - t0 < budget:
     e = float(sys.argv[3]) + float(torch.rand(1)) * float(sys.argv[4]) if len(sys.argv) > 4 else 3.0 + float(torch.rand(1)) * 4.6
     n = max(1, int(10 ** e))
     if torch.iinfo(it).bits == 64: n = min(n, 12_000_000)
-    kind = int(torch.randint(0, 8, (1,)))
+    kind = int(torch.randint(0, 14, (1,)))
+    # route knobs: the default, the routes considered at every length, and the A/B modes
+    mode = [1, 1, 7, 8, 10, 11, 3, 9][int(torch.randint(0, 8, (1,)))]
+    rdst_amd.set_hybrid(mode, 1 if int(torch.randint(0, 3, (1,))) else 0)
     total_keys += n; big += n > 1_000_000
     split, fast = bool(torch.randint(0, 2, (1,))), int(torch.randint(0, 3, (1,)))
     rs.set_tuning(chain_split=split, fast_rank=fast)
@@ -66,7 +84,8 @@ while time.time() - t0 < budget:
     runs += 1
     if not ok:
         fails += 1
-        print(f"FAIL {name} n={n} kind={kind} split={split} fast={fast}", flush=True)
+        print(f"FAIL {name} n={n} kind={kind} split={split} fast={fast} mode={mode} route={rdst_amd.last_route()}", flush=True)
     del src, keys, m, exp
 rs.set_tuning()
+rdst_amd.set_hybrid(True)
 print(f"stress: {runs} sorts ({big} above 10^6 keys, {total_keys:.3e} keys in all), {fails} failures", flush=True)
