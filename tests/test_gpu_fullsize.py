@@ -160,6 +160,11 @@ def test_keys_that_share_their_top_bits_take_the_atomic_route_through_a_lowered_
     stray = (r & 0x3FFFFFFF).clone()
     stray[123_456_789] = -1                      # 0xFFFFFFFF (no sampled position: they are multiples of n / 8192)
     cases.append(("uint32", stray, None))
+    g8 = torch.Generator(device="cuda").manual_seed(0x5D57000B)
+    r8 = torch.randint(-(2**63), 2**63 - 1, (300_000_000,), dtype=torch.int64, device="cuda", generator=g8)
+    cases.append(("uint64", (r8 & 0x1FFFFFFFFFFFFFFF) | 0x2000000000000000, "atomic"))   # one rank's share of 8, 8-byte keys
+    cases.append(("int64", r8 & 0x7FFFFFFFFFFFFFFF, "atomic"))
+    del r8
     for name, src, want in cases:
         keys = src.clone()
         s1, s2 = int(keys.sum()), int((keys ^ (keys >> 11)).sum())
