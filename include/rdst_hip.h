@@ -102,7 +102,7 @@ typedef enum {
 /* Device routes (rdst_hip_last_route). */
 #define RDST_ROUTE_LSD 0u     /* one scatter pass per level */
 #define RDST_ROUTE_HYBRID 1u  /* two scatter passes on the top 16 bits + one in-LDS sort per bucket */
-#define RDST_ROUTE_ATOMIC 2u  /* the same without the counting read: MSD passes that claim space with atomics (4-byte keys) */
+#define RDST_ROUTE_ATOMIC 2u  /* the same without the counting read: MSD passes that claim space with atomics */
 
 /* Options of the host entry point.  NULL = defaults. */
 typedef struct {
@@ -299,17 +299,20 @@ int rdst_hip_profile_run(int run, float* out_ms, uint32_t capacity, uint32_t* n_
  * inserts RDST_STAGE_HIST16 and RDST_STAGE_ROUTE after the clear and RDST_STAGE_LOCAL after the passes. */
 int rdst_hip_profile_run_stages(int run, uint32_t* stages_out, uint32_t capacity, uint32_t* n_out);
 
-/* Route choice.  Whole sorts of 4- and 8-byte keys with min_len <= len (and short enough that a uniform bucket fits one
- * tile of the in-LDS sort) try a route that moves fewer bytes than one scatter pass per level — the device form of rdst's
- * own MSD-then-Lsb route at this size (src/tuners/standard_tuner.rs:46-62 picks by length and counts, too):
- *   4-byte keys: the ATOMIC route — two MSD passes that claim space in over-provisioned areas with atomics (no counting
- *   read at all), then the in-LDS sort of every bucket; if an area overflows (keys far from uniform) the LSD route runs;
- *   8-byte keys: the HYBRID route — K1h counts the top 16 bits, two K3 passes, the in-LDS sort; LSD if a bucket is too large.
- * enabled == 0: LSD route always; 1: the default above; 7: the hybrid (K1h) route for 4-byte keys too;
- * 2 / 3 / 5 / 6: hybrid route for every width with one detail changed, for A/B runs and tests — 2: ranked in-LDS sort for
- * 4-byte keys as well, 3: pass L-1 hands K4 whole keys instead of 16-bit halves, 5: no key sample before K1h, 6: 8-byte keys
- * with the one-block-per-CU form of K4.  min_len == 0 keeps the built-in threshold (2^28).  Results are identical on every
- * route.  Not part of the reference surface. */
+/* Route choice.  Whole sorts of 4- and 8-byte keys with min_len <= len < 2^30 try routes that move fewer bytes than one
+ * scatter pass per level — the device form of rdst's own MSD-then-Lsb route at this size (SURVEY.md §3.1;
+ * src/tuners/standard_tuner.rs:46-62 picks by length and counts, too).  The device decides, in this order:
+ *   ATOMIC — two MSD passes that claim space in over-provisioned areas with atomics (no counting read at all), then the
+ *   in-LDS sort of every bucket; given up if an area or a slot overflows (keys far from uniform);
+ *   HYBRID — K1h counts the top 16 bits exactly, two K3 passes, the in-LDS sort; 8-byte keys: if every bucket fits one tile,
+ *   4-byte keys: buckets of any size (up to 4 096 of 65 536 keys and more);
+ *   LSD — everything else.
+ * enabled == 0: LSD route always; 1: the default above; 7: start at the hybrid route; 2 / 3 / 5 / 6 / 9: hybrid route for
+ * every width with one detail changed, for A/B runs and tests — 2: ranked in-LDS sort for 4-byte keys as well, 3: pass L-1
+ * hands K4 whole keys instead of 16-bit halves, 5: no key sample, 6: 8-byte keys with the one-block-per-CU form of K4, 9: no
+ * expanding K4 (4-byte buckets up to one tile only); 8: the atomic route for 4-byte keys only; 10: a failed atomic route
+ * falls straight to LSD; 11: no giant kernels.  min_len == 0 keeps the built-in threshold (2^28).  Results are identical
+ * on every route.  Not part of the reference surface. */
 int rdst_hip_set_hybrid(int enabled, uint64_t min_len);
 
 /* Route the most recent sort enqueued by this library on the current device took (RDST_ROUTE_*).  Blocks on `stream`. */

@@ -75,24 +75,29 @@ constexpr uint32_t RDST_FAST_RANK = 1u << 16;  // bit of the pass kernel's flag 
 constexpr uint32_t RDST_FAST_RANK_SELFTEST = 1u << 17;  // treat every round of the fast ranking as failed: exercises its fallback
 constexpr uint32_t ERR_LOOKBACK_TIMEOUT = 1;
 constexpr uint32_t ERR_SCATTER_RANGE = 2;  // a computed destination fell outside [0, n): never stored
-constexpr uint32_t ERR_LOCAL_OVERFLOW = 4;  // a bucket of the hybrid route larger than the local sort's tile: never sorted
+constexpr uint32_t ERR_LOCAL_OVERFLOW = 4;  // a bucket larger than the K4 kernel it reached can take (the routes' own tests rule it out): never sorted
 
-// Two routes through the kernels, chosen ON THE DEVICE from the counts of the key multiset — the device
-// form of Tuner::pick_algorithm(params, counts) (src/tuner.rs:33-35, src/sorter.rs:67-76):
-//   ROUTE_LSD     K1, K2, one K3 pass per level (k*(2L+1) bytes per key)
+// Three routes through the kernels, chosen ON THE DEVICE from a sample and the counts of the key multiset — the device
+// form of Tuner::pick_algorithm(params, counts) (src/tuner.rs:33-35, src/sorter.rs:67-76).  Tried in this order; the
+// host launches every kernel of every route, each looks at the plan first:
+//   ROUTE_ATOMIC  (4- and 8-byte keys, 2^28 <= n < 2^30) the hybrid route without its counting read.  An MSD pass needs no
+//                 stable order and no exact global offsets up front, only ROOM: pass A scatters by the top byte into
+//                 256 x 8 over-provisioned areas (XCD slice x digit) of the workspace, a tile claiming its space per digit
+//                 with ONE returning global atomic where K3 walks back over its predecessors; pass B scatters every area by
+//                 the second byte into 65 536 slots (4-byte keys: low halves only); K4 sorts each slot's bucket to its
+//                 exact place (exclusive scan of the 65 536 claim counters).  u32: 8 + 6 + 6 = 20 bytes per key, u64: 48.
+//                 Uniform keys never overflow an area (capacity = mean + max(1 %, 8 sigma)); a claim that does not fit
+//                 gives the route up.  Keys that share their top bits (the sample sees it, pass A checks it) are
+//                 bucketed by the 16 bits below those (Plan::win_shift).
 //   ROUTE_HYBRID  the shape of rdst's own 10^9-key route (two MSD levels, then Lsb on
-//                 ~15 k-key chunks, src/sorts/lsb_sort.rs:39-127): K1h counts the top 16 bits, two K3
+//                 ~15 k-key chunks, src/sorts/lsb_sort.rs:39-127) with exact counts: K1h counts the top 16 bits, two K3
 //                 passes order the slice by them (levels L-2, L-1), and K4 sorts every one of the
 //                 65 536 buckets by the remaining levels inside LDS — one read and one coalesced write
-//                 instead of L-2 scatter passes (u32: 28 instead of 36 bytes per key; u64: 56 instead
-//                 of 136).  Taken when every bucket fits K4's tile; anything else goes the LSD way.
-//   ROUTE_ATOMIC  (4-byte keys) the hybrid route without its counting read.  An MSD pass needs no stable order and no exact
-//                 global offsets up front, only ROOM: pass A scatters by the top byte into 256 x 8 over-provisioned areas
-//                 (XCD slice x digit) of the workspace, a tile claiming its space per digit with ONE returning global
-//                 atomic where K3 walks back over its predecessors; pass B scatters every area by the second byte into
-//                 65 536 slots of one K4 tile each (low halves only); K4 sorts each slot's bucket to its exact place
-//                 (exclusive scan of the 65 536 claim counters).  8 + 6 + 6 = 20 bytes per key.  Uniform keys never
-//                 overflow an area (capacity = mean + max(1 %, 8 sigma)); anything that does takes the LSD route.
+//                 instead of L-2 scatter passes (u32: 24 instead of 36 bytes per key; u64: 56 instead
+//                 of 136).  8-byte keys: when every bucket fits K4's tile.  4-byte keys: buckets of any size — up to
+//                 4 096 of them may hold 65 536 keys and more (the giant kernels) — unless more than a third of the keys
+//                 sit in buckets of one to four tiles.
+//   ROUTE_LSD     K1, K2, one K3 pass per level (k*(2L+1) bytes per key): everything else.
 constexpr uint32_t ROUTE_LSD = 0, ROUTE_HYBRID = 1, ROUTE_ATOMIC = 2;
 constexpr int MSD_SLICES = 8;  // areas per top digit in pass A: blocks b and b + 8 share an XCD, so a digit's 8 frontiers stay with one L2 each
 constexpr int H16_BINS = 65536;
@@ -104,7 +109,7 @@ struct Plan {
     uint32_t result_in_tmp;           // where the data sits after the last executed pass
     uint32_t executed;                // number of passes executed
     uint32_t first_level;             // lowest executed level: below it nothing has ordered the keys (order test of K3's fast ranking)
-    uint32_t route;                   // ROUTE_LSD or ROUTE_HYBRID (decided on the device by route_kernel)
+    uint32_t route;                   // ROUTE_ATOMIC (msd_finish_kernel), else ROUTE_HYBRID or ROUTE_LSD (route_kernel)
     uint32_t local_sort;              // hybrid route and the slice is not already sorted: K4 runs
     uint32_t gross_skew;              // a sample of the keys already rules the hybrid route out (presample_kernel): K1h returns at once
     uint32_t top_skew;                // the sample's top bytes are far from uniform: the atomic route's areas would overflow, its passes return at once
