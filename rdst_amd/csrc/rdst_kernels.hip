@@ -118,6 +118,11 @@ struct Plan {
     // rank's share of a sharded sort — so the 16 bits that make the 65 536 buckets start win_shift bits lower (pass A checks
     // every key against win_top; one that differs gives the route up)
     uint32_t win_shift, win_top;
+    // the sample flagged the keys (top_skew / gross_skew), so K1h counted them BEFORE the MSD passes and route_kernel has
+    // already decided: HYBRID — the two MSD passes then run in their exact form (claims on cursors that start at the exact
+    // offsets K1h's counts give: no room to run out of, no look-back, any distribution) in place of the two K3 passes — or LSD
+    uint32_t pre;
+    uint32_t pre_skip_a;  // ... and every key holds the same top byte (4-byte keys): the exact pass A would be a copy, pass B reads the slice itself
     uint32_t low_dups;                // (4-byte keys) the sample's low halves repeat: K4's first kernel (4-bit counters) would refuse most buckets, it hands them all on
     uint32_t sorted_known;            // K1h swept the whole slice and met no inversion: K1 need not read it again (K2 turns every pass off)
 };
@@ -542,8 +547,13 @@ __global__ __launch_bounds__(HIST_THREADS) void hist16_kernel(const K* __restric
                                                               uint32_t* __restrict__ h16 /* [65536] bucket counts */,
                                                               unsigned long long* __restrict__ hpos16 /* [2][CHAINS][256]: digits L-2 and L-1 per position range */,
                                                               uint32_t* __restrict__ inversion, uint32_t* __restrict__ overflow,
-                                                              const Plan* __restrict__ plan) {
+                                                              const Plan* __restrict__ plan, uint32_t pre_launch) {
     constexpr int W = sizeof(K) * 8;
+    if (pre_launch) {  // before the MSD passes: only if the sample flagged the keys (the atomic route will not be tried)
+        if (!(plan->top_skew || (GIANT && plan->gross_skew))) return;
+    } else if (plan->pre) {
+        return;  // counted already
+    }
     if (plan->gross_skew && !GIANT) return;  // the sample ruled the hybrid route out: K1 will count (and look for inversions) instead
     if (plan->route == ROUTE_ATOMIC) return;  // the atomic route was tried first and took the sort
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -713,6 +723,13 @@ struct RouteArgs {
     uint32_t* glist;        // [giant_max] out: the giants, in bucket order
     uint32_t* gcount_item;  // [giant_max + 1] out: first work item of each in the counting kernel (two per chunk of GIANT_CHUNK keys)
     uint32_t* gexp_item;    // [giant_max + 1] out: first work item of each in the expanding kernel (one per GIANT_OUT positions)
+    // the launch before the MSD passes (Plan::pre): on HYBRID it also sets the exact form of those passes up
+    uint32_t pre_launch;
+    uint32_t msd_tile;      // keys per tile of the MSD passes
+    uint32_t* cursor_a;     // [256] out: where top digit d's keys go in tmp (= its bucket start)
+    uint32_t* cursor_b;     // [65536] out: where bucket b's keys go (= bstart[b])
+    uint32_t* xtile0;       // [257] out: first tile of top digit d's region in pass B's grid
+    uint32_t skip_a_ok;     // pass B can read the caller's slice in place of pass A's output (4-byte keys: it writes halves elsewhere)
 };
 constexpr uint32_t GIANT_MIN = 65536;      // keys: below it the 16-bit counters of the LDS kernels do
 constexpr uint32_t GIANT_CHUNK = 1u << 19; // keys a block of the giant counting kernel streams per item (and value half), at least
@@ -729,9 +746,14 @@ constexpr uint32_t GIANT_OUT = 1u << 12;   // positions a block of the giant exp
 constexpr uint32_t GIANT_TABLE = H16_BINS + 16;  // words per giant: 65 536 counts / prefixes, then the total
 
 __global__ __launch_bounds__(1024) void route_kernel(RouteArgs a) {
-    __shared__ uint32_t s_wsum[16], s_wmax[16], s_wmid[16], s_wg[16], s_wci[16], s_wei[16];
+    __shared__ uint32_t s_wsum[16], s_wmax[16], s_wmid[16], s_wg[16], s_wci[16], s_wei[16], s_tiles[RADIX], s_tw[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (a.plan->route == ROUTE_ATOMIC) return;  // tried first, and it took the sort (msd_finish_kernel): nothing to decide
+    if (a.pre_launch) {
+        if (!(a.plan->top_skew || (a.giant_max && a.plan->gross_skew))) return;  // K1h did not run either: the atomic route goes first
+    } else if (a.plan->pre) {
+        return;  // decided before the MSD passes
+    }
     uint32_t c[64];
     const uint4* src = reinterpret_cast<const uint4*>(a.h16) + (size_t)tid * 16;
 #pragma unroll
@@ -806,6 +828,7 @@ __global__ __launch_bounds__(1024) void route_kernel(RouteArgs a) {
                         bmid * 3 <= a.n;  // (gross skew without the giant kernels: K1h returned at once, its counts are all zero)
     if (tid == 0) {
         a.plan->route = hybrid ? ROUTE_HYBRID : ROUTE_LSD;
+        if (a.pre_launch) a.plan->pre = 1;
         a.plan->sorted_known = ((giants_ok || a.plan->gross_skew == 0) && *a.inversion == 0 && a.allow_skip) ? 1u : 0u;
         a.plan->giants = hybrid ? tg : 0u;
         a.plan->giant_count_items = hybrid ? tci : 0u;
@@ -843,6 +866,41 @@ __global__ __launch_bounds__(1024) void route_kernel(RouteArgs a) {
     // level L-1, pair counts: (digit dh, group of the level L-2 digit)
     a.hpair[((size_t)top * CHAINS + 2 * q) * RADIX + dh] = sum0;
     a.hpair[((size_t)top * CHAINS + 2 * q + 1) * RADIX + dh] = sum1;
+    if (a.pre_launch) {
+        // the exact form of the MSD passes: every claim counter starts where its digit's / bucket's keys belong ...
+        uint32_t r2 = excl;
+        uint32_t* cb = a.cursor_b + (size_t)tid * 64;
+#pragma unroll
+        for (int k = 0; k < 64; ++k) { cb[k] = r2; r2 += c[k]; }
+        uint32_t dtot = mine;  // my digit's keys: four threads per top digit
+        dtot += __shfl_xor(dtot, 1);
+        dtot += __shfl_xor(dtot, 2);
+        if ((tid & 3) == 0) {
+            a.cursor_a[tid >> 2] = excl;  // (thread 4 d owns the digit's first 64 buckets: its exclusive sum is the digit's start)
+            s_tiles[tid >> 2] = (dtot + a.msd_tile - 1) / a.msd_tile;
+            if (a.skip_a_ok && (uint64_t)dtot == a.n) a.plan->pre_skip_a = 1;
+        }
+        __syncthreads();
+        // ... and pass B's grid: the tiles of digit d's region start at xtile0[d]
+        if (tid < RADIX) {
+            const uint32_t t = s_tiles[tid];
+            uint32_t it = t;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t y = __shfl_up(it, o);
+                if (lane >= o) it += y;
+            }
+            if (lane == 63) s_tw[wave] = it;
+            s_tiles[tid] = it - t;  // exclusive inside the wave
+        }
+        __syncthreads();
+        if (tid < RADIX) {
+            uint32_t off = 0;
+            for (int w = 0; w < wave; ++w) off += s_tw[w];
+            a.xtile0[tid] = s_tiles[tid] + off;
+            if (tid == RADIX - 1) a.xtile0[RADIX] = s_tw[0] + s_tw[1] + s_tw[2] + s_tw[3];
+        }
+    }
     // levels L-2 and L-1, per position range: as K1h counted them (pass L-1 normally runs second and takes its chains from the
     // pair counts; with a trivial level L-2 it runs first and splits by position)
     for (int j = tid; j < CHAINS * RADIX; j += 1024) {
@@ -866,6 +924,7 @@ struct MsdFinishArgs {
 __global__ __launch_bounds__(1024) void msd_finish_kernel(MsdFinishArgs a) {
     __shared__ uint32_t s_wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (a.plan->pre) return;  // the passes ran in their exact form for the hybrid route (or not at all): decided already
     const bool ok = a.plan->gross_skew == 0 && a.plan->top_skew == 0 && *a.overflow == 0;
     const bool sorted = ok && a.allow_skip && *a.inversion == 0;
     if (tid == 0) {
@@ -972,7 +1031,8 @@ __global__ __launch_bounds__(256 * SCAN_GROUPS) void scan_kernel(ScanArgs a) {
         // hybrid route: only the two top levels are scatter passes, K4 does the rest
         const bool hybrid = a.plan->route == ROUTE_HYBRID;
         const bool atomic_done = a.plan->route == ROUTE_ATOMIC;  // its own kernels did (or do) everything: no scatter pass of K3 runs
-        const uint32_t level_lo = hybrid ? a.levels - 2 : (atomic_done ? a.levels : a.level_lo);
+        const bool by_msd = hybrid && a.plan->pre != 0;  // the MSD passes ordered the slice by the top 16 bits (exact form): no K3 pass runs
+        const uint32_t level_lo = by_msd ? a.levels : (hybrid ? a.levels - 2 : (atomic_done ? a.levels : a.level_lo));
         if (!atomic_done) a.plan->local_sort = hybrid && !already_sorted ? 1u : 0u;
         for (uint32_t l = 0; l < MAX_LEVELS; ++l) {
             const bool active = l >= level_lo && l < a.level_hi && l < a.levels;
@@ -1745,14 +1805,24 @@ __global__ __launch_bounds__(NWAVES * 64, RDST_MSD_MINWAVES) void msd_scatter_ke
     uint32_t tiles_per_area, K* __restrict__ dst, uint16_t* __restrict__ dst16, uint32_t* __restrict__ cursor, uint32_t dst_cap, int shift,
     uint32_t slices /* areas per top digit (pass A: of the destination, pass B: of the source) */,
     const Plan* __restrict__ plan, uint32_t* __restrict__ overflow, uint32_t* __restrict__ inversion /* pass A sets it; pass B reads it */,
-    K neg, K pos) {
+    K neg, K pos,
+    // the exact form (Plan::pre, hybrid route): pass A keys -> xbuf by top digit, pass B xbuf -> buckets (4-byte keys: halves in
+    // dst16; 8-byte keys: whole keys in xout); the cursors start at the exact offsets (route_kernel), bstart / xtile0 give pass
+    // B's regions and grid
+    K* __restrict__ xbuf, K* __restrict__ xout, const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ xtile0) {
     static_assert(!HALVES || (SECOND && sizeof(K) == 4), "halves: the second pass of 4-byte keys");
     constexpr int BLOCK = NWAVES * 64, TILE = BLOCK * KPT;
     constexpr uint32_t SLOT_UNIT = (uint32_t)sizeof(K);
-    // the sample or an earlier tile already gave the route up (a coherent load: the flag is raised by blocks on other XCDs)
-    if (plan->gross_skew || plan->top_skew || ld_relaxed<uint32_t>(overflow)) return;
-    if (SECOND && *inversion == 0) return;      // pass A met no inversion: the slice is sorted, nothing to do
-    const int win = (int)plan->win_shift;       // the buckets' 16 bits start this far below the key's top (presample_kernel)
+    const bool exact = plan->pre != 0;  // block-uniform
+    if (exact) {
+        if (plan->route != ROUTE_HYBRID || plan->sorted_known) return;
+        if (!SECOND && plan->pre_skip_a) return;
+    } else {
+        // the sample or an earlier tile already gave the route up (a coherent load: the flag is raised by blocks on other XCDs)
+        if (plan->gross_skew || plan->top_skew || ld_relaxed<uint32_t>(overflow)) return;
+        if (SECOND && *inversion == 0) return;  // pass A met no inversion: the slice is sorted, nothing to do
+    }
+    const int win = exact ? 0 : (int)plan->win_shift;  // the buckets' 16 bits start this far below the key's top (presample_kernel)
     shift -= win;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* wave_hist = reinterpret_cast<uint32_t*>(smem);                           // [NWAVES][256]
@@ -1760,13 +1830,31 @@ __global__ __launch_bounds__(NWAVES * 64, RDST_MSD_MINWAVES) void msd_scatter_ke
     uint32_t* s_misc = reinterpret_cast<uint32_t*>(smem + NWAVES * 1024 + 1024);       // [32]
     K* s_keys = reinterpret_cast<K*>(smem + NWAVES * 1024 + 1024 + 128);               // [TILE]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t area = blockIdx.x / tiles_per_area, j = blockIdx.x % tiles_per_area;
-    const uint64_t acount = area_count ? (uint64_t)area_count[area] : n;
+    uint32_t area = blockIdx.x / tiles_per_area, j = blockIdx.x % tiles_per_area;
+    uint64_t acount = area_count ? (uint64_t)area_count[area] : n;
+    const K* asrc = src + (uint64_t)area * area_cap;
+    if (exact) {
+        if constexpr (!SECOND) {
+            area = 0; j = blockIdx.x; acount = n; asrc = src;
+        } else {  // the region of top digit d in xbuf: tiles xtile0[d] .. xtile0[d + 1]
+            if (blockIdx.x >= xtile0[RADIX]) return;
+            uint32_t d = 0;
+#pragma unroll
+            for (int b = 7; b >= 0; --b) {
+                const uint32_t c = d | (1u << b);
+                if (xtile0[c] <= blockIdx.x) d = c;
+            }
+            area = d; j = blockIdx.x - xtile0[d];
+            const uint32_t r0 = bstart[d * RADIX];
+            acount = bstart[(d + 1) * RADIX] - r0;
+            asrc = (plan->pre_skip_a ? static_cast<const K*>(xout) : static_cast<const K*>(xbuf)) + r0;  // (one top byte: pass A was skipped, the region is the slice itself)
+        }
+    }
     const uint64_t tile_off = (uint64_t)j * TILE;
     if (tile_off >= acount) return;
     const uint32_t valid = acount - tile_off < (uint64_t)TILE ? (uint32_t)(acount - tile_off) : (uint32_t)TILE;
     const bool full = valid == (uint32_t)TILE;
-    const K* tsrc = src + (uint64_t)area * area_cap + tile_off;
+    const K* tsrc = asrc + tile_off;
     __builtin_amdgcn_s_setprio(RDST_PRIO_LOAD);
     K mk[KPT];
     const uint32_t wbase = (uint32_t)wave * 64u * KPT + (uint32_t)lane;
@@ -1795,7 +1883,7 @@ __global__ __launch_bounds__(NWAVES * 64, RDST_MSD_MINWAVES) void msd_scatter_ke
             mk[i] = v;
         }
     }
-    if constexpr (!SECOND) {
+    if constexpr (!SECOND) if (!exact) {  // (exact form: K1h has looked for inversions already)
         if constexpr (MAPPED) edge = map_key<K>(edge, neg, pos);
         if (tile_off + (uint64_t)wave * 64u * KPT == 0) edge = 0;  // the slice's first key has no predecessor
         bool inv = false;
@@ -1823,11 +1911,24 @@ __global__ __launch_bounds__(NWAVES * 64, RDST_MSD_MINWAVES) void msd_scatter_ke
     const int bit0 = shift & 31;
     uint32_t uniform_rounds = 0;
     uint32_t run_index[(KPT + 1) / 2];
-    bool careful, fast;
+    bool careful, fast, heavy = false;
+    uint32_t hd = 0;
     {
         const uint32_t d0 = digit_of(mk[0], shift);
         const uint32_t dn = (uint32_t)__builtin_amdgcn_mov_dpp((int)d0, 0x138, 0xf, 0xf, false);
         careful = __builtin_popcountll(__builtin_amdgcn_ballot_w64(d0 == dn) & ~1ull) >= 8;
+        // one heavy digit (K3's step 3 has the same): its lanes rank by one ballot, the others by the returning add
+        if (careful && full) {
+            uint32_t best = 0;
+#pragma unroll
+            for (int probe = 0; probe < 3; ++probe) {
+                const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)d0, probe * 21);
+                const uint32_t k = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(d0 == c));
+                if (k > best) { best = k; hd = c; }
+            }
+            const uint64_t rest_rep = __builtin_amdgcn_ballot_w64(d0 == dn && d0 != hd) & ~1ull;
+            if (best >= 16 && __builtin_popcountll(rest_rep) < 8) { heavy = true; careful = false; }
+        }
         fast = !careful && full;  // any order inside a run will do (no order test) — but a partial tile's padding must stay BEHIND
                                   // the real keys of digit 255, which only the stable forms below guarantee
         if (careful) {
@@ -1842,6 +1943,26 @@ __global__ __launch_bounds__(NWAVES * 64, RDST_MSD_MINWAVES) void msd_scatter_ke
                     const uint32_t below = peers_below_total(digit_word<K>(mk[i], shift), bit0, total);
                     if (below == 0) atomicAdd(&wh[d], total);
                 }
+            }
+        } else if (fast && heavy) {
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                const uint32_t d = digit_of(mk[i], shift);
+                const uint64_t m = __builtin_amdgcn_ballot_w64(d == hd);
+                uint32_t r;
+                if (m != 0) {  // wave-uniform
+                    const int leader = __builtin_ctzll(m);
+                    uint32_t b = 0;
+                    if (lane == leader) b = atomicAdd(&wh[hd], (uint32_t)__builtin_popcountll(m));
+                    b = (uint32_t)__builtin_amdgcn_readlane((int)b, leader);
+                    const uint32_t within = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    r = d == hd ? b + within : atomicAdd(&wh[d], 1u);
+                } else {
+                    r = atomicAdd(&wh[d], 1u);
+                }
+                asm volatile("" : "+v"(r));
+                if (i & 1) run_index[i >> 1] |= r << 16;
+                else run_index[i >> 1] = r;
             }
         } else if (fast) {
 #pragma unroll
@@ -1891,18 +2012,19 @@ __global__ __launch_bounds__(NWAVES * 64, RDST_MSD_MINWAVES) void msd_scatter_ke
         // pass A: area (slice, digit) — blocks b and b + 8 share an XCD, so a digit's 8 frontiers stay with one L2 each, and the
         // tiles are dealt to the slices in turn: every slice gets its share of the keys give or take a tile;
         // pass B: slot (top digit of the source area, digit)
-        const uint32_t where = SECOND ? (area % RADIX) * RADIX + (uint32_t)tid : (blockIdx.x % slices) * RADIX + (uint32_t)tid;
+        const uint32_t where = SECOND ? (area % RADIX) * RADIX + (uint32_t)tid : (exact ? 0u : (blockIdx.x % slices) * RADIX) + (uint32_t)tid;
         uint32_t got = 0;
         if (pub) {
             // (Pass A has only 256 x 8 counters for ~59 000 tiles x 256 claims.  Measured: device-scope claims cost the pass nothing —
             // 1.555 ms against 1.554 with XCD-local workgroup-scope claims on per-XCD counters.)
             got = atomicAdd(&cursor[where], pub);
-            if (got + pub > dst_cap) {  // no room: give the route up, store nothing of this tile
+            if (!exact && got + pub > dst_cap) {  // no room: give the route up, store nothing of this tile
                 if (ld_relaxed<uint32_t>(overflow) == 0) atomicOr(overflow, 1u);  // (look first: thousands of tiles get here, see the inversion flag)
                 s_misc[1] = 1;
             }
         }
-        s_delta[tid] = where * dst_cap + got - local_off;  // (mod 2^32; the destination arrays hold fewer than 2^32 elements)
+        // (exact form: the counter started at the digit's / bucket's place in the destination — `got` is an element index)
+        s_delta[tid] = (exact ? 0u : where * dst_cap) + got - local_off;  // (mod 2^32; the destination arrays hold fewer than 2^32 elements)
     }
     __syncthreads();
     __builtin_amdgcn_s_setprio(0);
@@ -1963,7 +2085,7 @@ __global__ __launch_bounds__(NWAVES * 64, RDST_MSD_MINWAVES) void msd_scatter_ke
             if (full || p < valid) {
                 const uint32_t g = dd[i] + p;
                 if constexpr (HALVES) dst16[g] = (uint16_t)kk[i];
-                else dst[g] = MAPPED ? unmap_key<K>(kk[i], neg, pos) : kk[i];
+                else (exact ? (SECOND ? xout : xbuf) : dst)[g] = MAPPED ? unmap_key<K>(kk[i], neg, pos) : kk[i];
             }
         }
     }
@@ -3575,6 +3697,7 @@ struct Tuning {
     bool presample = true;              // a 65 536-key sample before K1h: gross skew goes straight to the LSD route
     bool wide2 = true;                  // 8-byte keys: K4 as two 512-thread blocks per CU (false: one 1024-thread block)
     bool atomic_route = true;           // 4-byte keys: try ROUTE_ATOMIC (no counting read) before anything else
+    bool exact_msd = true;              // behind a sample that flags the keys, K1h runs before the MSD passes and they take their exact form for the hybrid route
     bool giants = true;                 // 4-byte keys, hybrid route: buckets of 65 536 keys and more are sorted by the giant kernels (else: LSD route)
     bool chain_routes = true;           // behind a failed atomic route try the hybrid route before the LSD one
     bool expand = true;                 // 4-byte keys: buckets the counting K4 refuses go to the expanding one (any bucket below 65 536 keys)
@@ -3636,7 +3759,7 @@ struct Layout {
     uint32_t levels, tile, status_bytes;  // status_bytes: 4 or 8 per word
     uint64_t tiles;
     size_t off_err, off_tickets, off_plan, off_hpos, off_hpair, off_h16, off_hpos16, off_status, off_status_near, zero_bytes, off_hist, off_base,
-        off_cbase, off_chains, off_bstart, off_fblist, off_fblist2, off_glist, off_gsplit, off_gtables, off_halves, off_cursor_a, off_cursor_b, off_msd_a, total;
+        off_cbase, off_chains, off_bstart, off_fblist, off_fblist2, off_xtile0, off_glist, off_gsplit, off_gtables, off_halves, off_cursor_a, off_cursor_b, off_msd_a, total;
     uint32_t msd_cap_a, msd_slices;  // ROUTE_ATOMIC: keys an area of pass A holds; areas per top digit
     uint32_t slot_cap;               // and keys a bucket's slot (pass B's destination) holds
 };
@@ -3683,6 +3806,7 @@ Layout make_layout(uint64_t n, uint32_t elem_bytes, uint32_t levels, int cfg, ui
     L.off_bstart = o; o += sizeof(uint32_t) * ((size_t)H16_BINS + 4);     // hybrid route: bucket starts
     L.off_fblist = o; o += sizeof(uint32_t) * (size_t)H16_BINS;           // buckets the first K4 kernel hands on (count: header word 3)
     L.off_fblist2 = o; o += sizeof(uint32_t) * (size_t)H16_BINS;          // and those the second one hands on (count: header word 5)
+    L.off_xtile0 = o; o += sizeof(uint32_t) * (RADIX + 8);                  // exact form of the MSD passes: first tile of every top digit's region in pass B's grid
     L.off_glist = o; o += sizeof(uint32_t) * 3 * ((size_t)GIANT_MAX + 16); // giants of the hybrid route: buckets, first counting item, first expanding item
     o = align_up(o, 32);
     L.off_gsplit = o;
@@ -3877,7 +4001,7 @@ int launch_presample(const K* keys, uint64_t n, KeyMap km, Plan* plan, hipStream
 // K1h: the hybrid route's 65 536-bin count (same grid and pieces as K1)
 template <typename K>
 int launch_hist16(const K* keys, uint64_t n, uint32_t blocks, KeyMap km, uint32_t* h16, unsigned long long* hpos16, uint32_t* inversion,
-                  uint32_t* overflow, Plan* plan, hipStream_t s, bool sample_first = true, bool giant = false) {
+                  uint32_t* overflow, Plan* plan, hipStream_t s, bool sample_first = true, bool giant = false, uint32_t pre_launch = 0) {
     const bool aligned = (reinterpret_cast<uintptr_t>(keys) & 15u) == 0;
     const bool mapped = km.neg != 0 || km.pos != 0;
     if (sample_first)
@@ -3888,13 +4012,13 @@ int launch_hist16(const K* keys, uint64_t n, uint32_t blocks, KeyMap km, uint32_
     do {                                                                                                                   \
         if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&hist16_kernel<K, VEC, MAPPED>), lds)) return rc;       \
         hipLaunchKernelGGL((hist16_kernel<K, VEC, MAPPED>), dim3(blocks), dim3(HIST_THREADS), lds, s, keys, n, (K)km.neg,  \
-                           (K)km.pos, h16, hpos16, inversion, overflow, plan);                                             \
+                           (K)km.pos, h16, hpos16, inversion, overflow, plan, pre_launch);                                 \
     } while (0)
 #define RDST_H16G(VEC, MAPPED)                                                                                             \
     do {                                                                                                                   \
         if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&hist16_kernel<K, VEC, MAPPED, true>), lds)) return rc; \
         hipLaunchKernelGGL((hist16_kernel<K, VEC, MAPPED, true>), dim3(blocks), dim3(HIST_THREADS), lds, s, keys, n,       \
-                           (K)km.neg, (K)km.pos, h16, hpos16, inversion, overflow, plan);                                  \
+                           (K)km.neg, (K)km.pos, h16, hpos16, inversion, overflow, plan, pre_launch);                      \
     } while (0)
     if constexpr (sizeof(K) == 4) {
         if (giant) {
@@ -4236,6 +4360,45 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     const bool pair = g_tuning.chains && LEVELS >= 2 && level_hi > level_lo + 1;
     unsigned long long* hpair = reinterpret_cast<unsigned long long*>(ws + L.off_hpair);
     Plan* plan = reinterpret_cast<Plan*>(ws + L.off_plan);
+    // K1h + the route decision, launched twice behind a tried atomic route: before the MSD passes (they run only if the sample
+    // flagged the keys; the MSD passes then take their exact form for the hybrid route) and after them (what is left)
+    auto count_and_route = [&](uint32_t pre_launch, bool sample_first) -> int {
+      if constexpr (!HAS_V && (sizeof(K) == 4 || sizeof(K) == 8)) {
+        uint32_t* overflow16 = reinterpret_cast<uint32_t*>(ws + L.off_err) + 2;
+        uint32_t* h16 = reinterpret_cast<uint32_t*>(ws + L.off_h16);
+        unsigned long long* hpos16 = reinterpret_cast<unsigned long long*>(ws + L.off_hpos16);
+        if (int r = launch_hist16<K>(keys, n, (uint32_t)blocks, km, h16, hpos16, inversion, overflow16, plan, s, sample_first, giants, pre_launch)) return r;
+        if (!pre_launch)
+            if (int r = prof_mark(*D, s, RDST_STAGE_HIST16)) return r;
+        RouteArgs ra{};
+        ra.h16 = h16;
+        ra.hpos16 = hpos16;
+        ra.overflow = overflow16;
+        ra.inversion = inversion;
+        ra.allow_skip = allow_skip ? 1u : 0u;
+        ra.bstart = reinterpret_cast<uint32_t*>(ws + L.off_bstart);
+        ra.hpos = hpos;
+        ra.hpair = hpair;
+        ra.plan = plan;
+        ra.n = n;
+        ra.levels = (uint32_t)LEVELS;
+        ra.cap = sizeof(K) == 4 && g_tuning.count_sort && g_tuning.expand ? EXPAND_MAX : (uint32_t)local_tile(sizeof(K));
+        ra.giant_max = giants ? GIANT_MAX : 0u;
+        ra.glist = reinterpret_cast<uint32_t*>(ws + L.off_glist);
+        ra.gcount_item = ra.glist + GIANT_MAX + 16;
+        ra.gexp_item = ra.gcount_item + GIANT_MAX + 16;
+        ra.mid_tile = ra.cap == EXPAND_MAX && n >= (1u << 24) ? (uint32_t)COUNT16_TILE : 0u;  // (short slices: the test is not worth a wrong guess either way)
+        ra.pre_launch = pre_launch;
+        ra.msd_tile = (uint32_t)(MSD_WAVES * 64 * msd_kpt(sizeof(K)));
+        ra.cursor_a = reinterpret_cast<uint32_t*>(ws + L.off_cursor_a);
+        ra.cursor_b = reinterpret_cast<uint32_t*>(ws + L.off_cursor_b);
+        ra.xtile0 = reinterpret_cast<uint32_t*>(ws + L.off_xtile0);
+        ra.skip_a_ok = sizeof(K) == 4 ? 1u : 0u;
+        hipLaunchKernelGGL(route_kernel, dim3(1), dim3(1024), 0, s, ra);
+        HIP_TRY(hipGetLastError());
+      }
+        return RDST_OK;
+    };
     if constexpr (!HAS_V && (sizeof(K) == 4 || sizeof(K) == 8)) {
         if (try_atomic) {
             constexpr int KPT = msd_kpt(sizeof(K)), NW = MSD_WAVES, TILE = NW * 64 * KPT, W = (int)sizeof(K) * 8;
@@ -4250,6 +4413,12 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
             K* slots = HALF ? nullptr : reinterpret_cast<K*>(ws + L.off_halves);
             const bool mapped = km.neg != 0 || km.pos != 0;
             if ((rc = launch_presample<K>(keys, n, km, plan, s))) return rc;
+            if constexpr (sizeof(K) == 4 || sizeof(K) == 8) {
+                if (try_hybrid && g_tuning.exact_msd)
+                    if ((rc = count_and_route(1u, false))) return rc;
+            }
+            const uint32_t* bstart_x = reinterpret_cast<const uint32_t*>(ws + L.off_bstart);
+            const uint32_t* xtile0 = reinterpret_cast<const uint32_t*>(ws + L.off_xtile0);
             const uint32_t tiles_a = (uint32_t)((n + TILE - 1) / TILE);
             const uint32_t tpa = (L.msd_cap_a + TILE - 1) / TILE;
 #define RDST_MSD(MAPPED, SECOND, GRID, ...)                                                                                              \
@@ -4258,14 +4427,15 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
         hipLaunchKernelGGL((msd_scatter_kernel<K, KPT, NW, MAPPED, SECOND, (SECOND && HALF)>), dim3(GRID), dim3(NW * 64), mlds, s, __VA_ARGS__); \
     } while (0)
             // pass A: the slice, by its top byte, into 256 x 8 areas
-            if (mapped) RDST_MSD(true, false, tiles_a, keys, nullptr, n, 0u, tiles_a, area_a, nullptr, cursor_a, L.msd_cap_a, W - 8, L.msd_slices, plan, overflow, inversion, (K)km.neg, (K)km.pos);
-            else RDST_MSD(false, false, tiles_a, keys, nullptr, n, 0u, tiles_a, area_a, nullptr, cursor_a, L.msd_cap_a, W - 8, L.msd_slices, plan, overflow, inversion, (K)km.neg, (K)km.pos);
+            if (mapped) RDST_MSD(true, false, tiles_a, keys, nullptr, n, 0u, tiles_a, area_a, nullptr, cursor_a, L.msd_cap_a, W - 8, L.msd_slices, plan, overflow, inversion, (K)km.neg, (K)km.pos, tmp, keys, bstart_x, xtile0);
+            else RDST_MSD(false, false, tiles_a, keys, nullptr, n, 0u, tiles_a, area_a, nullptr, cursor_a, L.msd_cap_a, W - 8, L.msd_slices, plan, overflow, inversion, (K)km.neg, (K)km.pos, tmp, keys, bstart_x, xtile0);
             HIP_TRY(hipGetLastError());
             if ((rc = prof_mark(*D, s, RDST_STAGE_MSD_A))) return rc;
             // pass B: every area, by the second byte, into the slot of its bucket
-            const uint32_t grid_b = (uint32_t)RADIX * L.msd_slices * tpa;
-            if (mapped) RDST_MSD(true, true, grid_b, area_a, cursor_a, 0ull, L.msd_cap_a, tpa, slots, slots16, cursor_b, slot_cap, W - 16, L.msd_slices, plan, overflow, inversion, (K)km.neg, (K)km.pos);
-            else RDST_MSD(false, true, grid_b, area_a, cursor_a, 0ull, L.msd_cap_a, tpa, slots, slots16, cursor_b, slot_cap, W - 16, L.msd_slices, plan, overflow, inversion, (K)km.neg, (K)km.pos);
+            uint32_t grid_b = (uint32_t)RADIX * L.msd_slices * tpa;
+            if (grid_b < tiles_a + RADIX) grid_b = tiles_a + RADIX;  // (the exact form: every top digit's region ends on a partial tile)
+            if (mapped) RDST_MSD(true, true, grid_b, area_a, cursor_a, 0ull, L.msd_cap_a, tpa, slots, slots16, cursor_b, slot_cap, W - 16, L.msd_slices, plan, overflow, inversion, (K)km.neg, (K)km.pos, tmp, keys, bstart_x, xtile0);
+            else RDST_MSD(false, true, grid_b, area_a, cursor_a, 0ull, L.msd_cap_a, tpa, slots, slots16, cursor_b, slot_cap, W - 16, L.msd_slices, plan, overflow, inversion, (K)km.neg, (K)km.pos, tmp, keys, bstart_x, xtile0);
 #undef RDST_MSD
             HIP_TRY(hipGetLastError());
             if ((rc = prof_mark(*D, s, RDST_STAGE_MSD_B))) return rc;
@@ -4290,32 +4460,7 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     }
     if constexpr (!HAS_V && (sizeof(K) == 4 || sizeof(K) == 8)) {
         if (try_hybrid) {
-            uint32_t* overflow = reinterpret_cast<uint32_t*>(ws + L.off_err) + 2;
-            uint32_t* h16 = reinterpret_cast<uint32_t*>(ws + L.off_h16);
-            unsigned long long* hpos16 = reinterpret_cast<unsigned long long*>(ws + L.off_hpos16);
-            rc = launch_hist16<K>(keys, n, (uint32_t)blocks, km, h16, hpos16, inversion, overflow, plan, s, !try_atomic, giants);
-            if (rc) return rc;
-            if ((rc = prof_mark(*D, s, RDST_STAGE_HIST16))) return rc;
-            RouteArgs ra{};
-            ra.h16 = h16;
-            ra.hpos16 = hpos16;
-            ra.overflow = overflow;
-            ra.inversion = inversion;
-            ra.allow_skip = allow_skip ? 1u : 0u;
-            ra.bstart = reinterpret_cast<uint32_t*>(ws + L.off_bstart);
-            ra.hpos = hpos;
-            ra.hpair = hpair;
-            ra.plan = plan;
-            ra.n = n;
-            ra.levels = (uint32_t)LEVELS;
-            ra.cap = sizeof(K) == 4 && g_tuning.count_sort && g_tuning.expand ? EXPAND_MAX : (uint32_t)local_tile(sizeof(K));
-            ra.giant_max = giants ? GIANT_MAX : 0u;
-            ra.glist = reinterpret_cast<uint32_t*>(ws + L.off_glist);
-            ra.gcount_item = ra.glist + GIANT_MAX + 16;
-            ra.gexp_item = ra.gcount_item + GIANT_MAX + 16;
-            ra.mid_tile = ra.cap == EXPAND_MAX && n >= (1u << 24) ? (uint32_t)COUNT16_TILE : 0u;  // (short slices: the test is not worth a wrong guess either way)
-            hipLaunchKernelGGL(route_kernel, dim3(1), dim3(1024), 0, s, ra);
-            HIP_TRY(hipGetLastError());
+            if ((rc = count_and_route(0u, !try_atomic))) return rc;
             if (split_clear) {
                 const uint64_t vecs = level_rows * (LEVELS - 2) / 16;  // rows are multiples of 1 KiB
                 hipLaunchKernelGGL(clear_unless_hybrid_kernel, dim3((uint32_t)D->cus * 4), dim3(256), 0, s, plan,
@@ -4644,6 +4789,8 @@ int rdst_hip_set_hybrid(int enabled, uint64_t min_len) {
     g_tuning.presample = enabled != 5;   // 5: no sample before K1h: every hybrid-eligible sort counts all its keys' prefixes first (tests)
     g_tuning.wide2 = enabled != 6;       // 6: 8-byte keys with the one-block-per-CU form of K4 (A/B, tests)
     g_tuning.atomic_route = enabled == 1 || enabled == 8;  // 1: the default (4- and 8-byte keys try the atomic route first); 2..7: the K1h hybrid route for every key width (7: with the default forms of K4)
+    g_tuning.exact_msd = enabled != 12;    // 12: the default without the exact form of the MSD passes (the hybrid route's passes are K3's) (A/B, tests)
+    g_tuning.atomic_route = g_tuning.atomic_route || enabled == 12;
     g_tuning.giants = enabled != 11;       // 11: the default without the giant kernels (a bucket of 65 536 keys sends the sort down the LSD route) (A/B, tests)
     g_tuning.atomic_route = g_tuning.atomic_route || enabled == 11;
     g_tuning.chain_routes = enabled != 10; // 10: the default, but a failed atomic route falls straight to the LSD route (A/B, tests)

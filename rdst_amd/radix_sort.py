@@ -469,7 +469,7 @@ def set_hybrid(enabled=True, min_len=0):
     keys only (8-byte keys on the hybrid route); 9 the hybrid route without the expanding K4 (buckets up to one tile only);
     10 the default without the hybrid route as the atomic route's first fallback; 11 the default without the giant kernels
     (4-byte keys: a bucket of 65 536 keys and more sends the sort down the LSD route)."""
-    _lib.check(_lib.load().rdst_hip_set_hybrid(int(enabled) if enabled in (2, 3, 5, 6, 7, 8, 9, 10, 11) else int(bool(enabled)), int(min_len)))
+    _lib.check(_lib.load().rdst_hip_set_hybrid(int(enabled) if enabled in (2, 3, 5, 6, 7, 8, 9, 10, 11, 12) else int(bool(enabled)), int(min_len)))
 
 
 def last_route(device=None) -> str:

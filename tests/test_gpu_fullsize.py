@@ -99,9 +99,9 @@ def test_more_than_2_pow_30_keys_uses_wide_status_words(gpu):
 
 def test_skewed_full_size_inputs(gpu):
     """The reference's bimodal bench input (gen_inputs with shift 16, src/test_utils.rs:51-61 / benches/full_sort.rs:68-78) at
-    5·10^8 keys: half the keys share the 16-bit prefix 0.  The 8 192-key sample sees it: pass A of the atomic route returns at
-    once; K1h counts the slice exactly (a bucket of any size), the hybrid route's giant kernels sort that bucket and the
-    buckets of one value the other half makes are written at once.  An input with ONE bucket one key over the tile is invisible
+    5·10^8 keys: half the keys share the 16-bit prefix 0.  The 8 192-key sample sees it: K1h counts the slice exactly (a bucket
+    of any size) before the MSD passes, which then run in their exact form for the hybrid route (mode 7: K3's passes); the
+    hybrid route's giant kernels sort that bucket and the buckets of one value the other half makes are written at once.  An input with ONE bucket one key over the tile is invisible
     to the sample and is caught by the atomic route's own exact check (a slot claim that does not fit): the hybrid route takes it."""
     import torch
     n = 500_000_000
@@ -112,7 +112,7 @@ def test_skewed_full_size_inputs(gpu):
     for mode, first in ((True, "msd_pass_a"), (7, "histogram16")):
         gpu.set_hybrid(mode)
         try:
-            for name, inp, first_runs, route in (("bimodal", bimodal, first == "histogram16", "hybrid"), ("borderline", borderline, True, "hybrid")):
+            for name, inp, first_runs, route in (("bimodal", bimodal, True, "hybrid"), ("borderline", borderline, True, "hybrid")):
                 keys = inp.clone()
                 gpu.sort_device_tensor(keys.view(torch.uint32))   # first use of a kernel loads its code object: not timed
                 keys.copy_(inp)
