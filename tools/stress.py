@@ -39,6 +39,8 @@ def gen(n, it, kind):
         r = ((pick << (bits - 16)) | low).to(it)
     elif kind == 9 and bits == 32:                                    # a float column (sorted as whatever the type is)
         r = (torch.randn(n, dtype=torch.float32, device="cuda", generator=g) * float(10 ** (torch.rand(1) * 6 - 3))).view(torch.int32)
+    elif kind == 9 and bits == 64:
+        r = (torch.randn(n, dtype=torch.float64, device="cuda", generator=g) * float(10 ** (torch.rand(1) * 6 - 3))).view(torch.int64)
     elif kind == 10: r = torch.full_like(r, int(r[0]))               # one value
     elif kind == 11: r = torch.where(r > 0, r[:1], r[-1:])            # two values
     elif kind == 12 and bits >= 32:                                   # dense ids, shuffled
@@ -54,7 +56,8 @@ while time.time() - t0 < budget:
     name, it = types[int(torch.randint(0, len(types), (1,)))]
     e = float(sys.argv[3]) + float(torch.rand(1)) * float(sys.argv[4]) if len(sys.argv) > 4 else 3.0 + float(torch.rand(1)) * 4.6
     n = max(1, int(10 ** e))
-    if torch.iinfo(it).bits == 64: n = min(n, 12_000_000)
+    if torch.iinfo(it).bits == 64: n = min(n, 12_000_000 if not os.environ.get("RDST_STRESS_BIG64") else 450_000_000)
+    if os.environ.get("RDST_STRESS_TYPES") and name not in os.environ["RDST_STRESS_TYPES"].split(","): continue
     kind = int(torch.randint(0, 14, (1,)))
     # route knobs: the default, the routes considered at every length, and the A/B modes
     mode = [1, 1, 7, 8, 10, 11, 3, 9][int(torch.randint(0, 8, (1,)))]
