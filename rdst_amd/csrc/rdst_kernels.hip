@@ -726,7 +726,7 @@ struct RouteArgs {
     // the launch before the MSD passes (Plan::pre): on HYBRID it also sets the exact form of those passes up
     uint32_t pre_launch;
     uint32_t msd_tile;      // keys per tile of the MSD passes
-    uint32_t* cursor_a;     // [256] out: where top digit d's keys go in tmp (= its bucket start)
+    uint32_t* cursor_a;     // [8][256] out: where the keys of top digit d from position range r go in tmp
     uint32_t* cursor_b;     // [65536] out: where bucket b's keys go (= bstart[b])
     uint32_t* xtile0;       // [257] out: first tile of top digit d's region in pass B's grid
     uint32_t skip_a_ok;     // pass B can read the caller's slice in place of pass A's output (4-byte keys: it writes halves elsewhere)
@@ -876,8 +876,15 @@ __global__ __launch_bounds__(1024) void route_kernel(RouteArgs a) {
         dtot += __shfl_xor(dtot, 1);
         dtot += __shfl_xor(dtot, 2);
         if ((tid & 3) == 0) {
-            a.cursor_a[tid >> 2] = excl;  // (thread 4 d owns the digit's first 64 buckets: its exclusive sum is the digit's start)
-            s_tiles[tid >> 2] = (dtot + a.msd_tile - 1) / a.msd_tile;
+            // pass A claims per (position range, top digit): the digit's start (thread 4 d owns its first 64 buckets: its
+            // exclusive sum) + the digit's keys in the earlier ranges (K1h counted them per range)
+            uint32_t at = excl;
+            const uint32_t d = (uint32_t)tid >> 2;
+            for (int r = 0; r < CHAINS; ++r) {
+                a.cursor_a[r * RADIX + d] = at;
+                at += (uint32_t)a.hpos16[(size_t)(CHAINS + r) * RADIX + d];
+            }
+            s_tiles[d] = (dtot + a.msd_tile - 1) / a.msd_tile;
             if (a.skip_a_ok && (uint64_t)dtot == a.n) a.plan->pre_skip_a = 1;
         }
         __syncthreads();
@@ -1795,6 +1802,10 @@ ranked:
 // (top digit of the source area, digit) of dst_cap keys, low halves only (HALVES).  A claim that would pass the capacity
 // raises *overflow and stores nothing.  The key map is applied for the digit and, for whole keys, undone at the store.
 // ------------------------------------------------------------------------------------------
+struct MsdRanges {
+    uint64_t start[CHAINS + 1];  // K1h's position ranges: [start[r], start[r + 1])
+};
+
 // SECOND: pass B (sources are pass A's areas, destinations the bucket slots); HALVES: 4-byte keys' pass B stores low halves.
 template <typename K, int KPT, int NWAVES, bool MAPPED, bool SECOND, bool HALVES>
 #ifndef RDST_MSD_MINWAVES
@@ -1809,7 +1820,11 @@ __global__ __launch_bounds__(NWAVES * 64, RDST_MSD_MINWAVES) void msd_scatter_ke
     // the exact form (Plan::pre, hybrid route): pass A keys -> xbuf by top digit, pass B xbuf -> buckets (4-byte keys: halves in
     // dst16; 8-byte keys: whole keys in xout); the cursors start at the exact offsets (route_kernel), bstart / xtile0 give pass
     // B's regions and grid
-    K* __restrict__ xbuf, K* __restrict__ xout, const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ xtile0) {
+    K* __restrict__ xbuf, K* __restrict__ xout, const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ xtile0,
+    // exact pass A: the slice is cut at K1h's eight position ranges (their per-digit counts are exact: hpos16's second table), each
+    // range is tiled on its own and claims from its own 256 counters — block b works on range b % 8, so a range's tiles (and
+    // its frontiers) stay with one XCD, and a heavy digit's claims queue eight times shorter than on one counter
+    MsdRanges xr) {
     static_assert(!HALVES || (SECOND && sizeof(K) == 4), "halves: the second pass of 4-byte keys");
     constexpr int BLOCK = NWAVES * 64, TILE = BLOCK * KPT;
     constexpr uint32_t SLOT_UNIT = (uint32_t)sizeof(K);
@@ -1835,7 +1850,9 @@ __global__ __launch_bounds__(NWAVES * 64, RDST_MSD_MINWAVES) void msd_scatter_ke
     const K* asrc = src + (uint64_t)area * area_cap;
     if (exact) {
         if constexpr (!SECOND) {
-            area = 0; j = blockIdx.x; acount = n; asrc = src;
+            area = blockIdx.x % CHAINS; j = blockIdx.x / CHAINS;
+            acount = xr.start[area + 1] - xr.start[area];
+            asrc = src + xr.start[area];
         } else {  // the region of top digit d in xbuf: tiles xtile0[d] .. xtile0[d + 1]
             if (blockIdx.x >= xtile0[RADIX]) return;
             uint32_t d = 0;
@@ -1912,22 +1929,25 @@ __global__ __launch_bounds__(NWAVES * 64, RDST_MSD_MINWAVES) void msd_scatter_ke
     uint32_t uniform_rounds = 0;
     uint32_t run_index[(KPT + 1) / 2];
     bool careful, fast, heavy = false;
-    uint32_t hd = 0;
+    uint32_t hd3[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};  // wave-uniform
     {
         const uint32_t d0 = digit_of(mk[0], shift);
         const uint32_t dn = (uint32_t)__builtin_amdgcn_mov_dpp((int)d0, 0x138, 0xf, 0xf, false);
         careful = __builtin_popcountll(__builtin_amdgcn_ballot_w64(d0 == dn) & ~1ull) >= 8;
-        // one heavy digit (K3's step 3 has the same): its lanes rank by one ballot, the others by the returning add
+        // up to three heavy digits (a float column's sign-and-exponent byte: 50 % / 37 % / 9 % of the keys on three values;
+        // K3's step 3 has the one-digit form): their lanes rank by one ballot each, the others by the returning add.  The
+        // candidates are the digits of three probed lanes; a candidate that less than an eighth of the round holds is dropped.
         if (careful && full) {
-            uint32_t best = 0;
 #pragma unroll
             for (int probe = 0; probe < 3; ++probe) {
                 const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)d0, probe * 21);
                 const uint32_t k = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(d0 == c));
-                if (k > best) { best = k; hd = c; }
+                hd3[probe] = k >= 8 ? c : 0xFFFFFFFFu;  // (no digit is 0xFFFFFFFF: a dropped candidate matches nothing)
             }
-            const uint64_t rest_rep = __builtin_amdgcn_ballot_w64(d0 == dn && d0 != hd) & ~1ull;
-            if (best >= 16 && __builtin_popcountll(rest_rep) < 8) { heavy = true; careful = false; }
+            if (hd3[1] == hd3[0]) hd3[1] = 0xFFFFFFFFu;
+            if (hd3[2] == hd3[0] || hd3[2] == hd3[1]) hd3[2] = 0xFFFFFFFFu;
+            const uint64_t rest_rep = __builtin_amdgcn_ballot_w64(d0 == dn && d0 != hd3[0] && d0 != hd3[1] && d0 != hd3[2]) & ~1ull;
+            if ((hd3[0] & hd3[1] & hd3[2]) != 0xFFFFFFFFu && __builtin_popcountll(rest_rep) < 8) { heavy = true; careful = false; }
         }
         fast = !careful && full;  // any order inside a run will do (no order test) — but a partial tile's padding must stay BEHIND
                                   // the real keys of digit 255, which only the stable forms below guarantee
@@ -1945,25 +1965,30 @@ __global__ __launch_bounds__(NWAVES * 64, RDST_MSD_MINWAVES) void msd_scatter_ke
                 }
             }
         } else if (fast && heavy) {
+            // (the table is this wave's own: a heavy digit's lanes are ranked from a running count in a scalar register — no LDS
+            // round trip between the rounds — and the count is stored once at the end; the other lanes' digits are other words)
+            uint32_t run3[3] = {0, 0, 0};
 #pragma unroll
             for (int i = 0; i < KPT; ++i) {
                 const uint32_t d = digit_of(mk[i], shift);
-                const uint64_t m = __builtin_amdgcn_ballot_w64(d == hd);
-                uint32_t r;
-                if (m != 0) {  // wave-uniform
-                    const int leader = __builtin_ctzll(m);
-                    uint32_t b = 0;
-                    if (lane == leader) b = atomicAdd(&wh[hd], (uint32_t)__builtin_popcountll(m));
-                    b = (uint32_t)__builtin_amdgcn_readlane((int)b, leader);
-                    const uint32_t within = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    r = d == hd ? b + within : atomicAdd(&wh[d], 1u);
-                } else {
-                    r = atomicAdd(&wh[d], 1u);
+                uint32_t r = 0;
+                bool ranked = false;
+#pragma unroll
+                for (int h = 0; h < 3; ++h) {
+                    const uint64_t m = __builtin_amdgcn_ballot_w64(d == hd3[h]);
+                    if (d == hd3[h]) {
+                        r = run3[h] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                        ranked = true;
+                    }
+                    run3[h] += (uint32_t)__builtin_popcountll(m);
                 }
-                asm volatile("" : "+v"(r));
+                if (!ranked) r = atomicAdd(&wh[d], 1u);
                 if (i & 1) run_index[i >> 1] |= r << 16;
                 else run_index[i >> 1] = r;
             }
+#pragma unroll
+            for (int h = 0; h < 3; ++h)
+                if (lane == 0 && hd3[h] != 0xFFFFFFFFu) wh[hd3[h]] = run3[h];
         } else if (fast) {
 #pragma unroll
             for (int i = 0; i < KPT; ++i) {
@@ -2012,7 +2037,7 @@ __global__ __launch_bounds__(NWAVES * 64, RDST_MSD_MINWAVES) void msd_scatter_ke
         // pass A: area (slice, digit) — blocks b and b + 8 share an XCD, so a digit's 8 frontiers stay with one L2 each, and the
         // tiles are dealt to the slices in turn: every slice gets its share of the keys give or take a tile;
         // pass B: slot (top digit of the source area, digit)
-        const uint32_t where = SECOND ? (area % RADIX) * RADIX + (uint32_t)tid : (exact ? 0u : (blockIdx.x % slices) * RADIX) + (uint32_t)tid;
+        const uint32_t where = SECOND ? (area % RADIX) * RADIX + (uint32_t)tid : (exact ? area : blockIdx.x % slices) * RADIX + (uint32_t)tid;
         uint32_t got = 0;
         if (pub) {
             // (Pass A has only 256 x 8 counters for ~59 000 tiles x 256 claims.  Measured: device-scope claims cost the pass nothing —
@@ -4417,6 +4442,21 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
                 if (try_hybrid && g_tuning.exact_msd)
                     if ((rc = count_and_route(1u, false))) return rc;
             }
+            MsdRanges xr{};
+            uint32_t tiles_x = 0;  // exact pass A: eight ranges tiled on their own, block b -> range b % 8
+            {
+                const uint64_t xvec = (reinterpret_cast<uintptr_t>(keys) & 15u) == 0 ? 16 / sizeof(K) : 1;  // as launch_hist16 picks K1h's loads
+                const uint64_t xpiece = hist_piece(n, (uint32_t)blocks, (uint64_t)HIST_THREADS * xvec * 4);
+                for (int r = 0; r <= CHAINS; ++r) {
+                    const uint64_t at = (uint64_t)hist_first_block((uint32_t)r, (uint32_t)blocks) * xpiece;
+                    xr.start[r] = at < n ? at : n;
+                }
+                for (int r = 0; r < CHAINS; ++r) {
+                    const uint32_t t = (uint32_t)((xr.start[r + 1] - xr.start[r] + TILE - 1) / TILE);
+                    if (t > tiles_x) tiles_x = t;
+                }
+                tiles_x *= CHAINS;
+            }
             const uint32_t* bstart_x = reinterpret_cast<const uint32_t*>(ws + L.off_bstart);
             const uint32_t* xtile0 = reinterpret_cast<const uint32_t*>(ws + L.off_xtile0);
             const uint32_t tiles_a = (uint32_t)((n + TILE - 1) / TILE);
@@ -4427,15 +4467,16 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
         hipLaunchKernelGGL((msd_scatter_kernel<K, KPT, NW, MAPPED, SECOND, (SECOND && HALF)>), dim3(GRID), dim3(NW * 64), mlds, s, __VA_ARGS__); \
     } while (0)
             // pass A: the slice, by its top byte, into 256 x 8 areas
-            if (mapped) RDST_MSD(true, false, tiles_a, keys, nullptr, n, 0u, tiles_a, area_a, nullptr, cursor_a, L.msd_cap_a, W - 8, L.msd_slices, plan, overflow, inversion, (K)km.neg, (K)km.pos, tmp, keys, bstart_x, xtile0);
-            else RDST_MSD(false, false, tiles_a, keys, nullptr, n, 0u, tiles_a, area_a, nullptr, cursor_a, L.msd_cap_a, W - 8, L.msd_slices, plan, overflow, inversion, (K)km.neg, (K)km.pos, tmp, keys, bstart_x, xtile0);
+            const uint32_t grid_a = tiles_a > tiles_x ? tiles_a : tiles_x;
+            if (mapped) RDST_MSD(true, false, grid_a, keys, nullptr, n, 0u, grid_a, area_a, nullptr, cursor_a, L.msd_cap_a, W - 8, L.msd_slices, plan, overflow, inversion, (K)km.neg, (K)km.pos, tmp, keys, bstart_x, xtile0, xr);
+            else RDST_MSD(false, false, grid_a, keys, nullptr, n, 0u, grid_a, area_a, nullptr, cursor_a, L.msd_cap_a, W - 8, L.msd_slices, plan, overflow, inversion, (K)km.neg, (K)km.pos, tmp, keys, bstart_x, xtile0, xr);
             HIP_TRY(hipGetLastError());
             if ((rc = prof_mark(*D, s, RDST_STAGE_MSD_A))) return rc;
             // pass B: every area, by the second byte, into the slot of its bucket
             uint32_t grid_b = (uint32_t)RADIX * L.msd_slices * tpa;
             if (grid_b < tiles_a + RADIX) grid_b = tiles_a + RADIX;  // (the exact form: every top digit's region ends on a partial tile)
-            if (mapped) RDST_MSD(true, true, grid_b, area_a, cursor_a, 0ull, L.msd_cap_a, tpa, slots, slots16, cursor_b, slot_cap, W - 16, L.msd_slices, plan, overflow, inversion, (K)km.neg, (K)km.pos, tmp, keys, bstart_x, xtile0);
-            else RDST_MSD(false, true, grid_b, area_a, cursor_a, 0ull, L.msd_cap_a, tpa, slots, slots16, cursor_b, slot_cap, W - 16, L.msd_slices, plan, overflow, inversion, (K)km.neg, (K)km.pos, tmp, keys, bstart_x, xtile0);
+            if (mapped) RDST_MSD(true, true, grid_b, area_a, cursor_a, 0ull, L.msd_cap_a, tpa, slots, slots16, cursor_b, slot_cap, W - 16, L.msd_slices, plan, overflow, inversion, (K)km.neg, (K)km.pos, tmp, keys, bstart_x, xtile0, xr);
+            else RDST_MSD(false, true, grid_b, area_a, cursor_a, 0ull, L.msd_cap_a, tpa, slots, slots16, cursor_b, slot_cap, W - 16, L.msd_slices, plan, overflow, inversion, (K)km.neg, (K)km.pos, tmp, keys, bstart_x, xtile0, xr);
 #undef RDST_MSD
             HIP_TRY(hipGetLastError());
             if ((rc = prof_mark(*D, s, RDST_STAGE_MSD_B))) return rc;
