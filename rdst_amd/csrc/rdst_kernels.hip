@@ -1486,25 +1486,21 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8,
             }
         } else if (fast && heavy) {
             if constexpr (CAN_FAST && !PERSIST) {
+                // (the table is this wave's own: the heavy digit's lanes are ranked from a running count in a scalar register —
+                // no LDS round trip — and the count is stored once at the end; the other lanes' digits are other words)
+                uint32_t run_h = 0;
 #pragma unroll
                 for (int i = 0; i < KPT; ++i) {
                     const uint32_t d = digit_of(mk[i], shift);
                     const uint64_t m = __builtin_amdgcn_ballot_w64(d == hd);
                     uint32_t r;
-                    if (m != 0) {  // wave-uniform
-                        const int leader = __builtin_ctzll(m);
-                        uint32_t b = 0;
-                        if (lane == leader) b = atomicAdd(&wh[hd], (uint32_t)__builtin_popcountll(m));
-                        b = (uint32_t)__builtin_amdgcn_readlane((int)b, leader);
-                        const uint32_t within = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                        r = d == hd ? b + within : atomicAdd(&wh[d], 1u);
-                    } else {
-                        r = atomicAdd(&wh[d], 1u);
-                    }
-                    asm volatile("" : "+v"(r));  // finish the round here: its ballot is an SGPR pair, 22 of them alive at once spill
+                    if (d == hd) r = run_h + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    else r = atomicAdd(&wh[d], 1u);
+                    run_h += (uint32_t)__builtin_popcountll(m);
                     if (i & 1) run_index[i >> 1] |= r << 16;
                     else run_index[i >> 1] = r;
                 }
+                if (lane == 0) wh[hd] = run_h;
             }
         } else if (fast) {
             // the count doubles as the ranking: the returning add hands every key its index inside the
