@@ -1842,6 +1842,17 @@ __global__ __launch_bounds__(NWAVES * 64, RDST_MSD_MINWAVES) void msd_scatter_ke
     K* s_keys = reinterpret_cast<K*>(smem + NWAVES * 1024 + 1024 + 128);               // [TILE]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t area = blockIdx.x / tiles_per_area, j = blockIdx.x % tiles_per_area;
+    if constexpr (SECOND) {
+        // pass B of the atomic route: a slot (top digit d, second digit) is appended to by the tiles of d's eight areas.  Blocks b
+        // and b + 8 share an XCD: hand top digit d to XCD d mod 8, so that a slot's frontier line is completed in ONE L2 instead of
+        // going out to HBM in pieces from eight
+        if (!exact && slices == (uint32_t)CHAINS) {
+            const uint32_t x = blockIdx.x % CHAINS, k = blockIdx.x / CHAINS;
+            const uint32_t q = k / tiles_per_area;           // (digit of this XCD, slice)
+            j = k % tiles_per_area;
+            area = (q % CHAINS) * RADIX + (x + CHAINS * (q / CHAINS));
+        }
+    }
     uint64_t acount = area_count ? (uint64_t)area_count[area] : n;
     const K* asrc = src + (uint64_t)area * area_cap;
     if (exact) {
