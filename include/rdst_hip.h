@@ -96,7 +96,8 @@ typedef enum {
     RDST_STAGE_ROUTE = 7,    /* route decision + bucket starts */
     RDST_STAGE_LOCAL = 8,    /* K4: per-bucket sort of the remaining levels inside LDS (hybrid and atomic routes) */
     RDST_STAGE_MSD_A = 10,   /* atomic route: scatter by the top byte into over-provisioned areas (claims instead of counts) */
-    RDST_STAGE_MSD_B = 11    /* atomic route: scatter of every area by the second byte into the bucket slots (low halves) */
+    RDST_STAGE_MSD_B = 11,   /* atomic route: scatter of every area by the second byte into the bucket slots (low halves) */
+    RDST_STAGE_SAMPLE = 12   /* the 8 192-key sample (and, if it flags the keys, K1h + the route decision) before the MSD passes */
 } rdst_stage;
 
 /* Device routes (rdst_hip_last_route). */

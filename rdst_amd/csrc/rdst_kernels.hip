@@ -4449,6 +4449,7 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
                 if (try_hybrid && g_tuning.exact_msd)
                     if ((rc = count_and_route(1u, false))) return rc;
             }
+            if ((rc = prof_mark(*D, s, RDST_STAGE_SAMPLE))) return rc;
             MsdRanges xr{};
             uint32_t tiles_x = 0;  // exact pass A: eight ranges tiled on their own, block b -> range b % 8
             {

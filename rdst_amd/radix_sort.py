@@ -430,7 +430,7 @@ def profile_runs() -> int:
     return int(_lib.load().rdst_hip_profile_runs())
 
 
-STAGE_NAMES = {1: "clear", 2: "histogram", 3: "scan", 4: "pass", 5: "copy_back", 6: "histogram16", 7: "route", 8: "local_sort", 10: "msd_pass_a", 11: "msd_pass_b"}
+STAGE_NAMES = {1: "clear", 2: "histogram", 3: "scan", 4: "pass", 5: "copy_back", 6: "histogram16", 7: "route", 8: "local_sort", 10: "msd_pass_a", 11: "msd_pass_b", 12: "sample"}
 
 
 def profile_run(run: int, levels: int):

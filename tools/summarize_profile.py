@@ -102,6 +102,12 @@ if traces:
              if (k.startswith("onesweep_kernel.") or k.startswith("msd_scatter_kernel.")) and v["avg_ms_timed_steps"] > 0.3]
     if moved:
         summ["scatter_avg_ms_timed_steps_launches_that_moved_keys"] = round(sum(moved) / len(moved), 4)
+    # the kernel bench.py's roofline object is about (pass A of the atomic route, else a K3 pass): trace against the run's events
+    dom = summ["per_kernel_ms"].get("msd_scatter_kernel.pass_a")
+    if dom and dom["avg_ms_timed_steps"] > 0.3 and bench_line and "pass A" in bench_line["roofline"].get("kernel", ""):
+        summ["roofline_kernel_avg_ms_timed_steps_trace"] = dom["avg_ms_timed_steps"]
+        print("roofline kernel (msd_scatter_kernel, pass A): trace %.4f ms; bench events in the same run: %s ms" % (
+            dom["avg_ms_timed_steps"], bench_line["roofline"]["avg_launch_ms"]))
     summ["bench_line_of_the_same_run"] = bench_line
     json.dump(summ, open(f"profiles/{tag}_kernel_trace_summary.json", "w"), indent=1)
     print("scatter pass avg over the launches that moved keys (timed steps, trace): %s ms; bench events in the same run: %s ms" % (
