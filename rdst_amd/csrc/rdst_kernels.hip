@@ -1852,6 +1852,8 @@ __global__ __launch_bounds__(NWAVES * 64, RDST_MSD_MINWAVES) void msd_scatter_ke
             j = k % tiles_per_area;
             area = (q % CHAINS) * RADIX + (x + CHAINS * (q / CHAINS));
         }
+        // (the grid also covers the exact form's tiles: blocks past the last area have nothing to do here)
+        if (!exact && (blockIdx.x / tiles_per_area >= RADIX * slices || area >= RADIX * slices)) return;
     }
     uint64_t acount = area_count ? (uint64_t)area_count[area] : n;
     const K* asrc = src + (uint64_t)area * area_cap;

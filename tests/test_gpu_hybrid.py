@@ -238,6 +238,20 @@ def test_giant_buckets(hybrid):
         assert same_bits(got, reference_sorted(a))
 
 
+def test_pass_b_grid_larger_than_the_areas(gpu):
+    """lengths at which pass B's grid (sized for the exact form too: tiles + 256) exceeds 2 048 areas x tiles per area: the
+    blocks past the last area must do nothing (a randomized run caught them sorting what lies behind the claim counters)."""
+    gpu.set_hybrid(True, 1)
+    try:
+        for n in (30_405_504, 65_048_690, 99_514_889):
+            a = random_bits(n, "uint32", seed=n & 0xFFFF).copy()
+            got, route = _sort(gpu, a)
+            assert route == "atomic"
+            assert same_bits(got, reference_sorted(a)), n
+    finally:
+        gpu.set_hybrid(True, 0)
+
+
 def test_two_thousand_giants(hybrid):
     """2 048 prefixes of ~67 000 keys each (what 10^9 normally distributed f32 keys look like to the route): within the 4 096
     count tables; more giants than tables is test_gpu_fullsize.py's (it takes 6·10^8 keys)."""
