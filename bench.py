@@ -4,11 +4,14 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype u32|u64|f32]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+A bare `python bench.py --gpus N` (N > 1, no WORLD_SIZE in the environment) starts its own N ranks as fresh child
+processes (torch.distributed.run, 127.0.0.1) BEFORE anything touches the GPU, waits, and exits with their code; rank 0's
+JSON line goes to the inherited stdout.
 
 A step = one sort of the workload.  N == 1: `rdst_hip_sort_device` on 10^9 keys already in HBM.
-N > 1 (weak scaling): every rank holds 10^9 keys; one step = the sharded route (local top-digit
-histogram, all-gather of the 256 counts, top-digit scatter, all-to-all over RCCL/xGMI, local
-sort) — value = N * 10^9 * K keys / wall time.  Every step sorts a fresh unsorted copy that was
+N > 1 (weak scaling, BASELINE configs[4] "C5": u64 keys unless --dtype says otherwise): every rank holds 10^9 keys;
+one step = the sharded route (local top-digit histogram, all-gather of the 256 counts, top-digit scatter,
+all-to-all over RCCL/xGMI, local sort) — value = N * 10^9 * K keys / wall time.  Every step sorts a fresh unsorted copy that was
 placed in HBM before the timed region (no copies inside it).
 
 The JSON line also carries (protocol of SURVEY.md §8(d) / BASELINE.md §3-4):
@@ -19,7 +22,11 @@ The JSON line also carries (protocol of SURVEY.md §8(d) / BASELINE.md §3-4):
   kernels        the same for every stage of the route taken (K1h / K1, K3, K4 ...)
   copy_ceiling   a measured device copy of the same array (read + write), beside the 8 TB/s spec
   configs        N == 1: BASELINE configs[2] and [3] (10^9 u64, 10^9 f32) run after the timed region, same
-                 protocol, with their own roofline figures (B = 136 and 36 bytes per key)
+                 protocol, with their own roofline figures (B = 136 and 36 bytes per key); the inputs on which the
+                 default is NOT at its best (u32 on the forced LSD route, the reference's bimodal bench input,
+                 f32 normal(0, 1), reverse arange), each checked bit for bit against torch.sort of the mapped keys
+                 and timed beside the LSD-only setting; and u64_8e9 — 8 * 10^9 u64 keys on this one GPU, the
+                 denominator of C5's scaling target
   end_to_end     `rdst_hip_sort` on a host slice of the same workload (PCIe both ways) — never `value`
   cpu_baseline   the oracle (C restatement of rdst's StandardTuner route, OpenMP) timed on this box's host
                  cores on THE SAME ARRAY the GPU leg sorted; the two outputs are compared bit for bit
@@ -64,6 +71,20 @@ def cargo_probe():
         return out.stdout.strip() or "cargo present but silent"
     except Exception as e:  # noqa: BLE001
         return f"absent ({type(e).__name__})"
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: N ranks as children of torch.distributed.run on 127.0.0.1.
+    The parent only waits; rank 0 of the children prints the JSON line to the inherited stdout."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def cpu_baseline(host_keys, gpu_sorted_host):
@@ -175,6 +196,81 @@ def sort_level_fields(route, kb, levels, keys_per_gpu_per_s):
     return out
 
 
+def other_inputs(torch, n):
+    """The inputs on which the default route choice is not at its best: name -> (dtype name, maker).
+    bimodal = the reference's own bench input, gen_inputs(n, 16) (benches/bench_utils.rs:43-53, benches/full_sort.rs:68-70):
+    the first half of a uniform vector shifted right by 16, the second half left."""
+    def bimodal():
+        x = gen_keys(torch, n, "u32", 0x5D570006)
+        h = n // 2
+        x[:h] = (x[:h] >> 16) & 0xFFFF   # logical shift of the u32 bit pattern held in int32
+        x[h:] = x[h:] << 16
+        return x
+
+    def normal():
+        g = torch.Generator(device="cuda").manual_seed(0x5D570007)
+        return torch.randn(n, generator=g, device="cuda", dtype=torch.float32).view(torch.int32)
+
+    def reverse():
+        return torch.arange(n - 1, -1, -1, dtype=torch.int32, device="cuda")
+
+    return {"u32_bimodal_shift16": ("u32", bimodal), "f32_normal": ("f32", normal), "u32_reverse_arange": ("u32", reverse)}
+
+
+def exact_against_torch_sort(torch, src, out, name):
+    """bit-exact: rdst's key map is a bijection, so mapped(out) must equal torch.sort(mapped(src)) element for element"""
+    want = torch.sort(mapped_signed(torch, src, name)).values
+    got = mapped_signed(torch, out.view(src.dtype), name)
+    return bool(torch.equal(want, got))
+
+
+def mix_checksum(torch, x, chunk=1 << 27):
+    """(sum, sum of a bit-mixed image) of an int64 tensor, both mod 2^64, in bounded temporaries"""
+    a = b = 0
+    for s in range(0, x.numel(), chunk):
+        c = x[s:s + chunk]
+        a = (a + int(c.sum())) & (2**64 - 1)
+        m = (c * -7046029254386353131) ^ (c >> 29)
+        b = (b + int(m.sum())) & (2**64 - 1)
+    return a, b
+
+
+def big_u64_config(torch, rdst_amd, n_big):
+    """8 * 10^9 u64 keys on ONE GPU: the denominator of C5's scaling target; 64 GB + 64 GB tmp + the
+    unsorted source + the workspace (24 GB of 64-bit status rows) ~ 220 GB.  No clones: the buffer is refilled from the
+    source before every sort, outside the events."""
+    free, _total = torch.cuda.mem_get_info()
+    need = 3 * 8 * n_big + 40 * 2**30
+    if free < need:
+        return {"skipped": f"needs ~{need / 2**30:.0f} GiB of free HBM, {free / 2**30:.0f} available"}
+    src = gen_keys(torch, n_big, "u64", 0x5D570005)   # C5, rank 0's seed
+    buf = torch.empty_like(src).view(torch.uint64)
+    tmp = torch.empty_like(buf)
+    ms = []
+    for _ in range(3):   # the first one also allocates the workspace
+        buf.view(torch.int64).copy_(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rdst_amd.sort_device_tensor(buf, tmp, check=False)
+        e1.record()
+        torch.cuda.synchronize()
+        ms.append(e0.elapsed_time(e1))
+    rdst_amd.device_status()
+    route = rdst_amd.last_route()
+    out = buf.view(torch.int64)
+    ok_sorted = is_sorted(torch, mapped_signed(torch, out, "u64"))
+    ok_sum = mix_checksum(torch, out) == mix_checksum(torch, src)
+    assert ok_sorted and ok_sum, f"u64_8e9: sorted={ok_sorted} checksums_equal={ok_sum}"
+    best = min(ms[1:])
+    res = {"keys": n_big, "route": route, "ms_per_step": round(best, 3), "all_ms": [round(x, 3) for x in ms],
+           "Gkeys_per_s": round(n_big / best / 1e6, 3), "checked": "sortedness + two checksums against the input (outside the clock)",
+           **sort_level_fields(route, 8, 8, n_big / (best * 1e-3)),
+           "what": "BASELINE configs[4]'s single-GPU leg: 8e9 uniform u64 keys on one MI355X (best of 2 after a warm-up)"}
+    del src, buf, tmp, out
+    torch.cuda.empty_cache()
+    return res
+
+
 ROUTE_TEXT = {
     "atomic": "two MSD scatter passes that claim space with atomics (no counting read) + in-LDS sort of every bucket",
     "hybrid": "K1h (counts of the top 16 bits) + 2 scatter passes on them + in-LDS sort of every bucket",
@@ -218,11 +314,17 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--keys", type=int, default=KEYS_PER_GPU, help="keys per GPU (default: the BASELINE workload)")
-    ap.add_argument("--dtype", choices=sorted(DTYPES), default="u32", help="key type of the timed region (default: the headline u32)")
+    ap.add_argument("--dtype", choices=sorted(DTYPES), default=None,
+                    help="key type of the timed region (default: the headline u32 at N == 1; u64 — BASELINE configs[4], C5 — at N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the u64 / f32 configs, the copy ceiling and the end-to-end leg")
+    ap.add_argument("--no-extras", action="store_true", help="skip the other configs, the copy ceiling and the end-to-end leg")
+    ap.add_argument("--no-big", action="store_true", help="skip the 8 * 10^9-key u64 config (needs ~220 GB of HBM)")
     ap.add_argument("--route", choices=("auto", "lsd"), default="auto", help="lsd: never take the hybrid route (A/B)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: become one.  Nothing in this process has touched the GPU (torch is not even imported).
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -230,10 +332,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be started with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
+    if args.dtype is None:
+        args.dtype = "u32" if world == 1 else "u64"
     # rehearsal knobs (not used by the driver): several ranks on ONE GPU with gloo collectives, to
     # exercise the N > 1 code path on a single-GPU box (RCCL refuses two ranks on one device)
     backend = os.environ.get("RDST_BENCH_BACKEND", "nccl")
@@ -319,9 +420,10 @@ def main():
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(ms_per_step, 4),
             "median_ms_per_step": round(statistics.median(per_step), 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": name, "data": "synthetic",
-            "config": {"workload": f"{n} uniform-random {name} keys per GPU, device-resident; route '{route}': "
+            "config": {"workload": (f"C5 (BASELINE configs[4]) at {world} GPUs, weak: " if distributed and name == "u64" and n == KEYS_PER_GPU else "")
+                                   + f"{n} uniform-random {name} keys per GPU, device-resident; route '{route}': "
                                    + ROUTE_TEXT.get(route, f"LSD, {levels} passes x 8 bits")
-                                   + (", sharded: MSD top byte + RCCL all-to-all + local sort" if distributed else ""),
+                                   + (f", sharded: MSD top byte + all-gather of the 256 counts + all-to-all ({backend}) + local sort" if distributed else ""),
                        "keys_per_gpu": n, "total_keys": n * world, "seed": seed, "route": route,
                        "parallelism": f"shard{world}" if distributed else "single"},
             **sort_level_fields(route, kb, levels, total_keys / elapsed / world),
@@ -383,6 +485,45 @@ def main():
                 rdst_amd.set_profiling(False)
                 del src2, out2, bufs2, tmp2
                 torch.cuda.empty_cache()
+            # the inputs on which the default is not at its best, each beside the LSD-only setting of the same box
+            if n == KEYS_PER_GPU and name == "u32":
+                for cname, (dt, make) in other_inputs(torch, n).items():
+                    srcx = make()
+                    _vx, _npx, kbx, lvx, _sx = DTYPES[dt]
+                    el, ps, _runs, outx, bufsx, tmpx = timed_sorts(torch, rdst_amd, srcx, dt, 3, 1)
+                    rdst_amd.set_profiling(False)
+                    rt = rdst_amd.last_route()
+                    exact = exact_against_torch_sort(torch, srcx, outx, dt)
+                    assert exact, f"{cname}: device output differs from torch.sort of the mapped keys"
+                    del outx, bufsx, tmpx
+                    rdst_amd.set_hybrid(False)
+                    try:
+                        el_l, ps_l, _r, outl, bufsl, tmpl = timed_sorts(torch, rdst_amd, srcx, dt, 3, 1)
+                    finally:
+                        rdst_amd.set_profiling(False)
+                        rdst_amd.set_hybrid(True, 0)
+                    del outl, bufsl, tmpl
+                    configs[cname] = {"keys": n, "dtype": dt, "route": rt, "ms_per_step": round(statistics.median(ps), 4),
+                                      "Gkeys_per_s": round(n / statistics.median(ps) / 1e6, 3), "bit_exact_vs_torch_sort": exact,
+                                      "lsd_only_ms_per_step": round(statistics.median(ps_l), 4),
+                                      "default_over_lsd_only": round(statistics.median(ps) / statistics.median(ps_l), 4)}
+                    del srcx
+                    torch.cuda.empty_cache()
+                # the headline input on the forced LSD route (BASELINE configs[1] words it "LSD 4-pass")
+                rdst_amd.set_hybrid(False)
+                try:
+                    el_l, ps_l, runs_l, outl, bufsl, tmpl = timed_sorts(torch, rdst_amd, src, "u32", 3, 1)
+                    exact = exact_against_torch_sort(torch, src, outl, "u32")
+                    assert exact, "u32 on the LSD route: device output differs from torch.sort"
+                    configs["u32_forced_lsd"] = {"keys": n, "route": rdst_amd.last_route(), "ms_per_step": round(statistics.median(ps_l), 4),
+                                                 "Gkeys_per_s": round(n / statistics.median(ps_l) / 1e6, 3), "bit_exact_vs_torch_sort": exact,
+                                                 **sort_level_fields("lsd", 4, 4, n / (statistics.median(ps_l) * 1e-3)),
+                                                 "kernels": kernel_table(rdst_amd, runs_l, n, 4, 4)}
+                finally:
+                    rdst_amd.set_profiling(False)
+                    rdst_amd.set_hybrid(True, 0)
+                del outl, bufsl, tmpl
+                torch.cuda.empty_cache()
             line["configs"] = configs
             # end to end through the reference-shaped entry point: host slice in, host slice out (PCIe both ways)
             if host_keys is None:
@@ -406,6 +547,8 @@ def main():
             del h
         del src
         torch.cuda.empty_cache()
+        if not args.no_extras and not args.no_big and n == KEYS_PER_GPU:
+            line.setdefault("configs", {})["u64_8e9"] = big_u64_config(torch, rdst_amd, 8 * KEYS_PER_GPU)
         line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(host_keys, gpu_sorted_host)
     elif rank == 0:
         line["cpu_baseline"] = None

@@ -109,7 +109,7 @@ class RadixSortBuilder {  // src/radix_sort_builder.rs:8-158
         static_assert(RadixKey<T>::LEVELS != 0, "RadixKey must have at least 1 level");  // radix_sort_builder.rs:22
     }
     RadixSortBuilder& with_parallel(bool parallel) { multi_threaded_ = parallel; return *this; }
-    RadixSortBuilder& with_tuner(const tuner::Tuner* t) { tuner_ = t; device_default_ = false; return *this; }
+    RadixSortBuilder& with_tuner(const tuner::Tuner* t) { tuner_ = t; device_default_ = false; low_memory_ = false; return *this; }  // the last with_*tuner call wins (radix_sort_builder.rs:53-147)
     // with_low_mem_tuner (src/radix_sort_builder.rs:74-77) trades speed for memory in the reference (Ska / Regions instead of
     // the out-of-place sorts): so does the device route — the keys and a scratch of len / 64 elements instead of two arrays
     // (rdst_hip_sort_device_lowmem behind rdst_hip_opts::low_memory).  with_single_threaded_tuner selects among the

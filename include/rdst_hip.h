@@ -266,6 +266,13 @@ int rdst_pick_algorithm(int tuner_id, const rdst_tuning_params* p, const uint64_
 /* Bytes of device memory the workspace needs for a sort of `len` elements. */
 uint64_t rdst_hip_workspace_bytes(uint64_t len, uint32_t elem_bytes);
 
+/* The workspace is library-owned, one per device, grown on demand and kept between calls — the device twin of the
+ * `tmp_bucket` the reference allocates and drops inside every sort (src/sorts/lsb_sort.rs:53, :126): for 10^9-key slices
+ * it is 1.7 x the slice (the byte-saving routes' areas and slots).  This call gives it back (blocking: it waits for every
+ * queued sort of the current device); the next sort allocates again.  If the allocation of a large workspace fails, the sort
+ * takes the LSD route, whose workspace is an eighth of the slice, instead of failing. */
+int rdst_hip_release_workspace(void);
+
 /* Runtime knobs for experiments: pass_config selects the scatter-kernel shape (tile size and
  * LDS staging; negative = built-in default), hist_blocks_per_cu the histogram grid (<= 0 =
  * built-in).  Not part of the reference surface. */

@@ -22,6 +22,7 @@ from .radix_sort import (  # noqa: F401
     set_profiling,
     set_hybrid,
     last_route,
+    release_workspace,
     last_profile,
     profile_run,
     profile_runs,
@@ -38,5 +39,5 @@ from ._lib import RdstHipError  # noqa: F401
 __all__ = [
     "radix_sort_unstable", "radix_sort_builder", "RadixSortBuilder", "tuner", "RdstHipError",
     "sort_device_tensor", "sort_device_tensor_lowmem", "partition_device", "sort_host_array", "sort_host_records", "sort_pairs_device_tensor", "sort_records_by_key", "level_counts", "all_level_counts", "scatter_level",
-    "device_status", "set_tuning", "set_profiling", "set_hybrid", "last_route", "last_profile", "key_info",
+    "device_status", "set_tuning", "set_profiling", "set_hybrid", "last_route", "release_workspace", "last_profile", "key_info",
 ]

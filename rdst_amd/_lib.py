@@ -32,6 +32,7 @@ SYMBOLS = (
     "rdst_hip_split_top16_device",
     "rdst_pick_algorithm",
     "rdst_hip_workspace_bytes",
+    "rdst_hip_release_workspace",
     "rdst_hip_set_tuning",
     "rdst_hip_set_chain_split",
     "rdst_hip_set_fast_rank",
@@ -105,6 +106,7 @@ def load():
     lib.rdst_pick_algorithm.argtypes = [ci, ctypes.POINTER(TuningParamsC), u64p, u64]
     lib.rdst_hip_workspace_bytes.argtypes = [u64, u32]
     lib.rdst_hip_workspace_bytes.restype = u64
+    lib.rdst_hip_release_workspace.argtypes = []
     lib.rdst_hip_set_tuning.argtypes = [ci, ci]
     lib.rdst_hip_set_chain_split.argtypes = [ci]
     lib.rdst_hip_set_fast_rank.argtypes = [ci]

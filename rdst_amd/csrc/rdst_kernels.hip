@@ -86,7 +86,7 @@ constexpr uint32_t ERR_LOCAL_OVERFLOW = 4;  // a bucket larger than the K4 kerne
 //                 with ONE returning global atomic where K3 walks back over its predecessors; pass B scatters every area by
 //                 the second byte into 65 536 slots (4-byte keys: low halves only); K4 sorts each slot's bucket to its
 //                 exact place (exclusive scan of the 65 536 claim counters).  u32: 8 + 6 + 6 = 20 bytes per key, u64: 48.
-//                 Uniform keys never overflow an area (capacity = mean + max(1 %, 8 sigma)); a claim that does not fit
+//                 Uniform keys never overflow an area (capacity = mean + max(1 / 8, 8 sigma)); a claim that does not fit
 //                 gives the route up.  Keys that share their top bits (the sample sees it, pass A checks it) are
 //                 bucketed by the 16 bits below those (Plan::win_shift).
 //   ROUTE_HYBRID  the shape of rdst's own 10^9-key route (two MSD levels, then Lsb on
@@ -125,6 +125,10 @@ struct Plan {
     uint32_t pre_skip_a;  // ... and every key holds the same top byte (4-byte keys): the exact pass A would be a copy, pass B reads the slice itself
     uint32_t low_dups;                // (4-byte keys) the sample's low halves repeat: K4's first kernel (4-bit counters) would refuse most buckets, it hands them all on
     uint32_t sorted_known;            // K1h swept the whole slice and met no inversion: K1 need not read it again (K2 turns every pass off)
+    // the sample says the counts would send the sort down the LSD route anyway (most keys in buckets of one to four tiles, more
+    // giants than tables; 8-byte keys: a bucket over the tile): neither the atomic route nor K1h is tried — the slice is not
+    // read twice for counting, which is what made such inputs slower than the LSD-only setting
+    uint32_t predict_lsd;
 };
 
 // top 16 bits (of the mapped key) of the keys of bucket b: b itself, or — atomic route with a lowered window — the shared top
@@ -454,7 +458,9 @@ constexpr uint32_t PRESAMPLE_DUP_LIMIT = 5000;
 constexpr uint32_t PRESAMPLE_TOP_LIMIT = 2 * PRESAMPLE_KEYS / RADIX;  // twice a top byte's share of the sample (Poisson(32) >= 64: 2e-7)
 
 template <typename K, bool MAPPED>
-__global__ __launch_bounds__(1024) void presample_kernel(const K* __restrict__ keys, uint64_t n, K neg, K pos, Plan* __restrict__ plan, uint32_t limit) {
+__global__ __launch_bounds__(1024) void presample_kernel(const K* __restrict__ keys, uint64_t n, K neg, K pos, Plan* __restrict__ plan, uint32_t limit,
+                                                         uint32_t mid_lo /* 4-byte keys: buckets over this many keys ... */, uint32_t mid_hi /* ... and below this cost more than the LSD route saves (0: no such class) */,
+                                                         uint32_t giant_max /* 4-byte keys: count tables for buckets of mid_hi keys and more */, uint32_t bucket_cap /* 8-byte keys: the largest bucket K4 takes */) {
     constexpr int W = sizeof(K) * 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* s_c = reinterpret_cast<uint32_t*>(smem);               // 65 536 8-bit counters, four per word
@@ -464,7 +470,7 @@ __global__ __launch_bounds__(1024) void presample_kernel(const K* __restrict__ k
     const int tid = threadIdx.x;
     for (int i = tid; i < H16_BINS / 4; i += 1024) { s_c[i] = 0; s_low[i] = 0; }
     if (tid < RADIX) s_top[tid] = 0;
-    if (tid < 4) s_skew[tid] = 0;
+    if (tid < 8) s_skew[tid] = 0;  // ([4] / [5] are set below, before their first use)
     const uint64_t step = n / PRESAMPLE_KEYS;
     bool skew = false;
     static_assert(PRESAMPLE_KEYS == 8 * 1024, "eight keys per thread, one batch");
@@ -513,7 +519,27 @@ __global__ __launch_bounds__(1024) void presample_kernel(const K* __restrict__ k
     // the atomic route's areas hold a top byte's share of the keys plus a percent: a byte with twice its share of the sample
     // would overflow its areas a third of the way through pass A — that route is not tried (the hybrid one is)
     if (tid < RADIX && s_top[tid] >= PRESAMPLE_TOP_LIMIT) s_skew[1] = 1;
+    // Where would exact counts send this sort?  A top byte that drew s samples holds about n * s / 8 192 keys; if they spread
+    // evenly over its 256 buckets, each holds est = that / 256.  (They need not — a bimodal input puts half the slice into ONE
+    // bucket — so only classes that a spread-out byte cannot leave by being lumpier are predicted: lumpier means bigger.)
+    if (tid < RADIX) {
+        const uint32_t hits = s_top[tid];
+        const uint64_t est = n * hits / ((uint64_t)PRESAMPLE_KEYS * RADIX);
+        if constexpr (sizeof(K) == 4) {
+            // [6] samples in bytes whose buckets look like one to four tiles, [7] such bytes at giant size (256 giants each)
+            if (mid_hi && hits >= 8 && est > (uint64_t)mid_lo + mid_lo / 4 && est + est / 4 < (uint64_t)mid_hi) atomicAdd(&s_skew[6], hits);
+            if (mid_hi && hits >= 8 && est >= (uint64_t)mid_hi + mid_hi / 4) atomicAdd(&s_skew[7], 1u);
+        } else {
+            if (bucket_cap && hits >= 16 && est > (uint64_t)bucket_cap * 2) s_skew[3] = 1;  // some bucket of that byte is over the tile for sure
+        }
+    }
     __syncthreads();
+    if (tid == 0) {
+        bool lsd = false;
+        if constexpr (sizeof(K) == 4) lsd = mid_hi && ((uint64_t)s_skew[6] * 5 > (uint64_t)PRESAMPLE_KEYS * 2 || (uint64_t)s_skew[7] * RADIX > (uint64_t)giant_max + giant_max / 2);
+        else lsd = s_skew[3] != 0;
+        if (lsd) plan->predict_lsd = 1;
+    }
     if (tid == 0 && s_skew[0]) plan->gross_skew = 1;
     if (tid == 0 && s_skew[1]) plan->top_skew = 1;
     if (tid == 0 && s_skew[2] >= PRESAMPLE_DUP_LIMIT) plan->low_dups = 1;
@@ -555,6 +581,7 @@ __global__ __launch_bounds__(HIST_THREADS) void hist16_kernel(const K* __restric
         return;  // counted already
     }
     if (plan->gross_skew && !GIANT) return;  // the sample ruled the hybrid route out: K1 will count (and look for inversions) instead
+    if (plan->predict_lsd) return;            // ... or predicts that the counts would (route_kernel then leaves the route at LSD)
     if (plan->route == ROUTE_ATOMIC) return;  // the atomic route was tried first and took the sort
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* s_h = reinterpret_cast<uint32_t*>(smem);
@@ -749,6 +776,7 @@ __global__ __launch_bounds__(1024) void route_kernel(RouteArgs a) {
     __shared__ uint32_t s_wsum[16], s_wmax[16], s_wmid[16], s_wg[16], s_wci[16], s_wei[16], s_tiles[RADIX], s_tw[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (a.plan->route == ROUTE_ATOMIC) return;  // tried first, and it took the sort (msd_finish_kernel): nothing to decide
+    if (a.plan->predict_lsd) return;            // K1h did not count: the route stays LSD (the cleared plan / msd_finish_kernel)
     if (a.pre_launch) {
         if (!(a.plan->top_skew || (a.giant_max && a.plan->gross_skew))) return;  // K1h did not run either: the atomic route goes first
     } else if (a.plan->pre) {
@@ -932,7 +960,7 @@ __global__ __launch_bounds__(1024) void msd_finish_kernel(MsdFinishArgs a) {
     __shared__ uint32_t s_wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (a.plan->pre) return;  // the passes ran in their exact form for the hybrid route (or not at all): decided already
-    const bool ok = a.plan->gross_skew == 0 && a.plan->top_skew == 0 && *a.overflow == 0;
+    const bool ok = a.plan->gross_skew == 0 && a.plan->top_skew == 0 && a.plan->predict_lsd == 0 && *a.overflow == 0;
     const bool sorted = ok && a.allow_skip && *a.inversion == 0;
     if (tid == 0) {
         a.plan->route = ok ? ROUTE_ATOMIC : ROUTE_LSD;
@@ -1829,9 +1857,13 @@ __global__ __launch_bounds__(NWAVES * 64, RDST_MSD_MINWAVES) void msd_scatter_ke
         if (plan->route != ROUTE_HYBRID || plan->sorted_known) return;
         if (!SECOND && plan->pre_skip_a) return;
     } else {
-        // the sample or an earlier tile already gave the route up (a coherent load: the flag is raised by blocks on other XCDs)
-        if (plan->gross_skew || plan->top_skew || ld_relaxed<uint32_t>(overflow)) return;
+        // the sample already gave the route up (plan words and pass A's inversion flag are written by EARLIER launches: block-uniform)
+        if (plan->gross_skew || plan->top_skew || plan->predict_lsd) return;
         if (SECOND && *inversion == 0) return;  // pass A met no inversion: the slice is sorted, nothing to do
+        // ... or an earlier tile did (a coherent load: the flag is raised by blocks on other XCDs WHILE this kernel runs, so two
+        // waves of one block can see different values — the exit must be the block's, not the wave's: a wave that left alone
+        // would leave its stale wave_hist table to be summed into the claims of the waves that stayed)
+        if (__syncthreads_or((int)ld_relaxed<uint32_t>(overflow))) return;
     }
     const int win = exact ? 0 : (int)plan->win_shift;  // the buckets' 16 bits start this far below the key's top (presample_kernel)
     shift -= win;
@@ -3737,6 +3769,7 @@ struct Tuning {
     bool expand = true;                 // 4-byte keys: buckets the counting K4 refuses go to the expanding one (any bucket below 65 536 keys)
     bool atomic_wide = true;            // ROUTE_ATOMIC for 8-byte keys too (whole keys in the slots)
     bool persist_fallback = true;       // behind the atomic route the LSD passes run as persistent blocks (cheap to skip)
+    bool predict = true;                // the sample may predict the LSD route (Plan::predict_lsd): neither MSD passes nor K1h are tried
     uint64_t hybrid_min_len = 1ull << 28;  // below this the buckets are too small for one workgroup each to pay off
 };
 uint32_t g_ablate = 0;  // only ever set by the RDST_EXPERIMENTS build
@@ -3862,12 +3895,15 @@ Layout make_layout(uint64_t n, uint32_t elem_bytes, uint32_t levels, int cfg, ui
     L.msd_slices = 1;
     if (want_msd) {
         // areas of pass A: tiles are dealt to the slices in turn, so a slice gets its share of the keys give or take a tile;
-        // capacity = mean + max(1 %, 8 sigma) + two tiles' worth of one digit, whole 64s.  Few tiles: one slice.
+        // capacity = mean + max(1 / 8, 8 sigma) + two tiles' worth of one digit, whole 64s.  Few tiles: one slice.
+        // (An eighth of slack, 0.5 GB per 10^9 u32 keys: dense ids below a bound that is no power of two — 10^9 of 2^30: the
+        // populated top digits hold 7 % over the mean — stay on this route; with 1 % they overflowed an area, were counted by
+        // K1h, made more giants than tables and ended on the LSD route, slower than the LSD-only setting.)
         const uint64_t TILE = (uint64_t)MSD_WAVES * 64 * msd_kpt(elem_bytes);
         const uint64_t tiles = (n + TILE - 1) / TILE;
         L.msd_slices = tiles >= 64 * MSD_SLICES ? MSD_SLICES : 1;
         const double mean = (double)n / (RADIX * L.msd_slices);
-        const double slack = mean * 0.01 > 8.0 * __builtin_sqrt(mean) ? mean * 0.01 : 8.0 * __builtin_sqrt(mean);
+        const double slack = mean * 0.125 > 8.0 * __builtin_sqrt(mean) ? mean * 0.125 : 8.0 * __builtin_sqrt(mean);
         L.msd_cap_a = (uint32_t)(((uint64_t)(mean + slack) + 2 * TILE / RADIX + 64) / 64 * 64);
         o += align_up((size_t)elem_bytes * L.msd_cap_a * RADIX * L.msd_slices, 256);
     }
@@ -3916,9 +3952,17 @@ int ensure_workspace(DeviceState& D, size_t bytes) {
         D.ws = nullptr;
         D.ws_bytes = 0;
     }
-    const size_t want = align_up(bytes + bytes / 8, 1 << 20);
-    HIP_TRY(hipMalloc(&D.ws, want));
+    // head room so that slightly longer slices do not re-allocate; none for the big layouts (the atomic route's workspace is
+    // 1.7 x the slice: an eighth of that on top is gigabytes)
+    size_t want = align_up(bytes + (bytes < ((size_t)1 << 30) ? bytes / 8 : 0), 1 << 20);
+    hipError_t e = hipMalloc(&D.ws, want);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // (not sticky: the caller may retry with a leaner layout)
+        D.ws = nullptr;
+        return fail(RDST_ERR_HIP, "hipMalloc(workspace)", e);
+    }
     D.ws_bytes = want;
+    D.last_plan_valid = false;
     return RDST_OK;
 }
 
@@ -4021,12 +4065,17 @@ int launch_presample(const K* keys, uint64_t n, KeyMap km, Plan* plan, hipStream
     const bool mapped = km.neg != 0 || km.pos != 0;
     const uint32_t limit = 12u + (uint32_t)(4ull * (uint64_t)local_tile(sizeof(K)) * PRESAMPLE_KEYS / n);
     constexpr size_t plds = presample_lds_bytes();
+    // what route_kernel will hold against the exact counts (RouteArgs::mid_tile, giant_max, cap), for the sample's prediction
+    const bool big4 = sizeof(K) == 4 && g_tuning.count_sort && g_tuning.expand && g_tuning.predict;
+    const uint32_t mid_lo = big4 ? (uint32_t)COUNT16_TILE : 0u, mid_hi = big4 ? GIANT_MIN : 0u;
+    const uint32_t giant_max = big4 && g_tuning.giants && n < (1ull << 30) ? GIANT_MAX : 0u;
+    const uint32_t bucket_cap = sizeof(K) == 8 && g_tuning.predict ? (uint32_t)local_tile(8) : 0u;
     if (mapped) {
         if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&presample_kernel<K, true>), plds)) return rc;
-        hipLaunchKernelGGL((presample_kernel<K, true>), dim3(1), dim3(1024), plds, s, keys, n, (K)km.neg, (K)km.pos, plan, limit);
+        hipLaunchKernelGGL((presample_kernel<K, true>), dim3(1), dim3(1024), plds, s, keys, n, (K)km.neg, (K)km.pos, plan, limit, mid_lo, mid_hi, giant_max, bucket_cap);
     } else {
         if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&presample_kernel<K, false>), plds)) return rc;
-        hipLaunchKernelGGL((presample_kernel<K, false>), dim3(1), dim3(1024), plds, s, keys, n, (K)km.neg, (K)km.pos, plan, limit);
+        hipLaunchKernelGGL((presample_kernel<K, false>), dim3(1), dim3(1024), plds, s, keys, n, (K)km.neg, (K)km.pos, plan, limit, mid_lo, mid_hi, giant_max, bucket_cap);
     }
     HIP_TRY(hipGetLastError());
     return RDST_OK;
@@ -4330,20 +4379,37 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     // enough that 65 536 tiles can hold it): K1h counts the buckets, route_kernel decides.  If it says LSD,
     // K1 runs as ever (the slice is then read twice for counting); if it says hybrid, K1 returns at once.
     const bool whole_sort = !HAS_V && level_lo == 0 && level_hi == (uint32_t)LEVELS && allow_skip && copy_back;
-    const bool try_atomic = whole_sort && atomic_eligible(n, sizeof(K), cfg);
-    // 8-byte keys: the fallback's passes run as persistent blocks of shape 5 (eight skipped passes of one block per tile cost 0.5 ms per 10^9 keys)
-    if (try_atomic && sizeof(K) == 8 && g_tuning.persist_fallback && g_tuning.pass_cfg < 0) cfg = 5;
-    // Behind a failed atomic route (an area or a slot overflowed) the hybrid route is tried next — exact counts, any bucket
-    // the local sort takes — and the LSD route last.  One launch sequence serves all three: every kernel looks at the plan.
-    const bool halves_cfg = g_tuning.halves && g_tuning.count_sort && halves_possible<K>(cfg, n);
-    const bool try_hybrid = whole_sort && hybrid_eligible(n, sizeof(K)) && (!try_atomic || (g_tuning.chain_routes && (sizeof(K) == 8 || halves_cfg)));
-    const bool halves = try_hybrid && halves_cfg;
-    // 4-byte keys: the hybrid route takes buckets of any size (K1h counts them exactly, the giant kernels of K4 sort them)
-    const bool giants = try_hybrid && sizeof(K) == 4 && g_tuning.giants && g_tuning.count_sort && g_tuning.expand && n < (1ull << 30);
-    const Layout L = make_layout(n, sizeof(K), LEVELS, cfg, HAS_V ? PAIR_WAVES * 64 * pair_kpt(sizeof(K), ValBytes<V>::value) : 0, halves, try_atomic, giants);
-    if (L.tiles >= (1ull << 31)) return fail(RDST_ERR_ARG, "len too large for one launch");
-    rc = ensure_workspace(*D, L.total);
+    // which routes this sort may take, and the workspace that needs.  `lean`: the LSD route only (0.13 x the slice instead of
+    // 1.7 x) — what is left when the device cannot spare the space of the byte-saving routes.
+    struct RoutePick { bool try_atomic, try_hybrid, halves, giants; int cfg; Layout L; };
+    const int cfg0 = cfg;
+    auto pick_routes = [&](bool lean) -> RoutePick {
+        RoutePick r{};
+        r.cfg = cfg0;
+        r.try_atomic = !lean && whole_sort && atomic_eligible(n, sizeof(K), r.cfg);
+        // 8-byte keys: the fallback's passes run as persistent blocks of shape 5 (eight skipped passes of one block per tile cost 0.5 ms per 10^9 keys)
+        if (r.try_atomic && sizeof(K) == 8 && g_tuning.persist_fallback && g_tuning.pass_cfg < 0) r.cfg = 5;
+        // Behind a failed atomic route (an area or a slot overflowed) the hybrid route is tried next — exact counts, any bucket
+        // the local sort takes — and the LSD route last.  One launch sequence serves all three: every kernel looks at the plan.
+        const bool halves_cfg = g_tuning.halves && g_tuning.count_sort && halves_possible<K>(r.cfg, n);
+        r.try_hybrid = !lean && whole_sort && hybrid_eligible(n, sizeof(K)) && (!r.try_atomic || (g_tuning.chain_routes && (sizeof(K) == 8 || halves_cfg)));
+        r.halves = r.try_hybrid && halves_cfg;
+        // 4-byte keys: the hybrid route takes buckets of any size (K1h counts them exactly, the giant kernels of K4 sort them)
+        r.giants = r.try_hybrid && sizeof(K) == 4 && g_tuning.giants && g_tuning.count_sort && g_tuning.expand && n < (1ull << 30);
+        r.L = make_layout(n, sizeof(K), LEVELS, r.cfg, HAS_V ? PAIR_WAVES * 64 * pair_kpt(sizeof(K), ValBytes<V>::value) : 0, r.halves, r.try_atomic, r.giants);
+        return r;
+    };
+    RoutePick rp = pick_routes(false);
+    if (rp.L.tiles >= (1ull << 31)) return fail(RDST_ERR_ARG, "len too large for one launch");
+    rc = ensure_workspace(*D, rp.L.total);
+    if (rc && (rp.try_atomic || rp.try_hybrid)) {  // no room for the areas and slots: the LSD route needs an eighth of the slice
+        rp = pick_routes(true);
+        rc = ensure_workspace(*D, rp.L.total);
+    }
     if (rc) return rc;
+    const bool try_atomic = rp.try_atomic, try_hybrid = rp.try_hybrid, halves = rp.halves, giants = rp.giants;
+    cfg = rp.cfg;
+    const Layout L = rp.L;
     char* ws = static_cast<char*>(D->ws);
     const KeyMap km = key_map_for(kind, sizeof(K));
     rc = workspace_acquire(*D, s);
@@ -4861,9 +4927,25 @@ int rdst_hip_last_route(void* stream, uint32_t* route_out) {
     *route_out = RDST_ROUTE_LSD;
     if (!D->ws || !D->last_plan_valid) return RDST_OK;  // no pipeline yet (or the one-workgroup sort)
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if ((rc = workspace_acquire(*D, s))) return rc;  // the sort may have run on another stream
     HIP_TRY(hipMemcpyAsync(D->host_err + 4, static_cast<char*>(D->ws) + D->last_plan_off + offsetof(Plan, route), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     *route_out = D->host_err[4];
+    return RDST_OK;
+}
+
+int rdst_hip_release_workspace(void) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    DeviceState* D;
+    int rc = current_device_state(&D);
+    if (rc) return rc;
+    if (!D->ws) return RDST_OK;
+    HIP_TRY(hipDeviceSynchronize());  // sorts still queued on any stream use it
+    HIP_TRY(hipFree(D->ws));
+    D->ws = nullptr;
+    D->ws_bytes = 0;
+    D->last_plan_valid = false;
+    D->have_last = false;
     return RDST_OK;
 }
 
@@ -5148,13 +5230,17 @@ int rdst_hip_sort(void* host_data, uint64_t len, uint32_t elem_bytes, rdst_key_k
     if (!D->host_stream && (e = hipStreamCreateWithFlags(&D->host_stream, hipStreamNonBlocking)) != hipSuccess)
         return done(fail(RDST_ERR_HIP, "hipStreamCreate", e));
     hipStream_t s = D->host_stream;
-    // RDST_HOST_ALLOC=pool re-creates the allocation scheme of commit 74cafa2 (one stream-ordered pool allocation
-    // per call) — kept only so that the abort that version once produced can be examined
+    // (The allocation scheme of commit 74cafa2 — one stream-ordered pool allocation per call — produced the round-1 abort
+    // examined in DESIGN.md §5; it exists only in the tools build, behind RDST_HOST_ALLOC=pool*, never in the product.)
+#ifdef RDST_EXPERIMENTS
     static const char* alloc_mode = getenv("RDST_HOST_ALLOC");
     static const bool use_pool = alloc_mode && strncmp(alloc_mode, "pool", 4) == 0;
     static const bool pool_sync = alloc_mode && strcmp(alloc_mode, "pool_sync") == 0;    // + stream sync between H2D and the sort
     static const bool host_debug = getenv("RDST_HOST_DEBUG") != nullptr;                // print the buffers of every call
     static const bool pool_nofree = alloc_mode && strcmp(alloc_mode, "pool_nofree") == 0;  // blocks are never returned: no recycling
+#else
+    constexpr bool use_pool = false, pool_sync = false, host_debug = false, pool_nofree = false;
+#endif
     void* pool_buf = nullptr;
     if (use_pool) {
         if ((e = hipMallocAsync(&pool_buf, half + second, s)) != hipSuccess) return done(fail(RDST_ERR_HIP, "hipMallocAsync(keys + tmp)", e));

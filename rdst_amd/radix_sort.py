@@ -17,7 +17,7 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from .tuner import Algorithm, GpuTuner, LowMemoryTuner, SingleThreadedTuner, Tuner, TuningParams
+from .tuner import Algorithm, GpuTuner, LowMemoryTuner, SingleThreadedTuner, StandardTuner, Tuner, TuningParams
 
 # dtype name -> (rdst_key_kind, elem_bytes); LEVELS == elem_bytes for every built-in type
 _KEY_TABLE = {
@@ -293,7 +293,10 @@ class RadixSortBuilder:
             collective = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         except Exception:  # noqa: BLE001
             collective = False
-        if n <= 1 and not collective:  # radix_sort_builder.rs:151 (a rank's shard of a distributed array may be empty)
+        # radix_sort_builder.rs:151.  Only a custom tuner can answer GpuSharded (the stock ones and the default device
+        # tuner never do): only then may an empty or one-key shard have to take part in a collective sort.
+        custom = not isinstance(self._tuner, (GpuTuner, LowMemoryTuner, SingleThreadedTuner, StandardTuner))
+        if n <= 1 and not (collective and custom):
             return
         if isinstance(self._tuner, LowMemoryTuner) and not self._key:
             # with_low_mem_tuner(): the reference trades speed for memory (Ska / Regions instead of the out-of-place
@@ -313,10 +316,23 @@ class RadixSortBuilder:
             counts = top_level_counts(self._data)
             algo = self._tuner.pick_algorithm(
                 TuningParams(threads=1, level=levels - 1, total_levels=levels, input_len=n, parent_len=None), counts)
-            if algo not in (Algorithm.GpuLsd, Algorithm.GpuSharded):
-                raise NotImplementedError(
-                    f"tuner picked {Algorithm(algo).name}: the CPU algorithms stay in the reference crate; "
-                    "this package implements the device routes (Algorithm.GpuLsd, Algorithm.GpuSharded) only")
+        if collective and custom and _is_torch_tensor(self._data):
+            # GpuSharded is collective: every rank must take it or none (a rank that stays out leaves the others waiting in
+            # the all-gather for ever).  One small all-reduce settles it; disagreement raises on EVERY rank.
+            import torch
+            import torch.distributed as dist
+            dev = self._data.device if dist.get_backend() == "nccl" else "cpu"
+            votes = torch.tensor([int(algo == Algorithm.GpuSharded), int(algo != Algorithm.GpuSharded)], dtype=torch.int32, device=dev)
+            dist.all_reduce(votes)
+            yes, no = (int(v) for v in votes.cpu())
+            if yes and no:
+                raise RuntimeError(f"the tuner answered Algorithm.GpuSharded on {yes} rank(s) and something else on {no}: a tuner that "
+                                   "can route to the sharded sort must answer identically on all ranks (decide on world-level "
+                                   "quantities, not on the local shard)")
+        if algo is not None and algo not in (Algorithm.GpuLsd, Algorithm.GpuSharded):
+            raise NotImplementedError(
+                f"tuner picked {Algorithm(algo).name}: the CPU algorithms stay in the reference crate; "
+                "this package implements the device routes (Algorithm.GpuLsd, Algorithm.GpuSharded) only")
         if algo == Algorithm.GpuSharded:
             import torch.distributed as dist
             if not (dist.is_available() and dist.is_initialized()):
@@ -470,6 +486,14 @@ def set_hybrid(enabled=True, min_len=0):
     10 the default without the hybrid route as the atomic route's first fallback; 11 the default without the giant kernels
     (4-byte keys: a bucket of 65 536 keys and more sends the sort down the LSD route)."""
     _lib.check(_lib.load().rdst_hip_set_hybrid(int(enabled) if enabled in (2, 3, 5, 6, 7, 8, 9, 10, 11, 12) else int(bool(enabled)), int(min_len)))
+
+
+def release_workspace(device=None) -> None:
+    """Give the library-owned device workspace back (rdst_hip_release_workspace): the byte-saving routes keep 1.7 x the
+    slice between calls.  Blocking; the next sort allocates again."""
+    import torch
+    with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
+        _lib.check(_lib.load().rdst_hip_release_workspace())
 
 
 def last_route(device=None) -> str:

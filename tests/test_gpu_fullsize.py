@@ -174,3 +174,61 @@ def test_keys_that_share_their_top_bits_take_the_atomic_route_through_a_lowered_
         assert int(keys.sum()) == s1 and int((keys ^ (keys >> 11)).sum()) == s2, name
         assert _is_sorted(torch, _mapped(torch, keys, np.dtype(name).kind)), name
         del keys
+
+
+def _sum_pair(torch, x, chunk=1 << 28):
+    """two wrapping checksums in bounded temporaries"""
+    a = b = 0
+    for s in range(0, x.numel(), chunk):
+        c = x[s:s + chunk]
+        a = (a + int(c.sum(dtype=torch.int64))) & (2**64 - 1)
+        b = (b + int((c ^ (c >> 11)).sum(dtype=torch.int64))) & (2**64 - 1)
+    return a, b
+
+
+def test_eight_billion_u64_keys_on_one_gpu(gpu):
+    """BASELINE configs[4]'s single-GPU leg (the 8-GPU figure is divided by "1 GPU, 8·10^9 u64"): n ~ 2^33 —
+    element indices and status-word prefixes past 2^32, 24 GB of 64-bit status rows, 64 GB + 64 GB of keys.  Same
+    size-independent properties as test_one_billion_keys: per-level histograms unchanged, two checksums, sortedness.  The
+    source is not kept (keys + tmp + workspace ~ 155 GB)."""
+    import torch
+    n = 8_000_000_000
+    free, _ = torch.cuda.mem_get_info()
+    assert free > 170 * 2**30, f"needs ~170 GiB of free HBM, {free / 2**30:.0f} available"
+    keys = _gen(torch, n, torch.int64, 0x5D570005)
+    view = keys.view(torch.uint64)
+    before = gpu.all_level_counts(view)
+    sums = _sum_pair(torch, keys)
+    gpu.sort_device_tensor(view)
+    gpu.device_status()
+    after = gpu.all_level_counts(view)
+    assert np.array_equal(before, after)
+    assert int(before[0].sum()) == n
+    assert _sum_pair(torch, keys) == sums
+    mn = torch.iinfo(torch.int64).min
+    for s in range(0, n, 1 << 27):   # (chunks: no n-sized temporaries)
+        e = min(n, s + (1 << 27) + 1)
+        c = keys[s:e] ^ mn
+        assert bool((c[1:] >= c[:-1]).all()), f"inversion in [{s}, {e})"
+    # the same through the numpy statement of the key order, on the slice's two ends and a stretch across index 2^32
+    from helpers import mapped_key
+    for lo in (0, (1 << 32) - 500_000, n - 1_000_000):
+        k = mapped_key(keys[lo:lo + 1_000_000].cpu().numpy().view("uint64"))
+        assert (k[1:] >= k[:-1]).all()
+
+
+def test_more_than_2_pow_32_u32_keys(gpu):
+    """4-byte keys past 2^32 ELEMENTS (17 GB + 17 GB): 64-bit destinations in every pass, tile starts past 2^32."""
+    import torch
+    n = (1 << 32) + 54_321
+    keys = _gen(torch, n, torch.int32, 0x5D57000C)
+    view = keys.view(torch.uint32)
+    before = gpu.all_level_counts(view)
+    sums = _sum_pair(torch, keys)
+    gpu.sort_device_tensor(view)
+    gpu.device_status()
+    assert np.array_equal(before, gpu.all_level_counts(view))
+    assert _sum_pair(torch, keys) == sums
+    assert _is_sorted(torch, _mapped(torch, keys, "u"))
+    tail = keys[n - 100_000:].cpu().numpy().view("uint32")   # the last tile lies wholly past element 2^32
+    assert (tail[1:] >= tail[:-1]).all() and int(tail[-1]) >= 0xFFFF0000

@@ -21,10 +21,11 @@ KERNELS = ("msd_scatter_kernel", "msd_finish_kernel", "presample_kernel", "onesw
 
 
 def short(name):
-    for k in KERNELS:
-        if k in name:
-            return k
-    return None
+    """kernel base name: `void (anonymous namespace)::local_wide2_sort_kernel<true>(...)` -> local_wide2_sort_kernel; torch's own
+    kernels (fills, copies, the generator) are left out"""
+    import re
+    m = re.match(r"^(?:void )?\(anonymous namespace\)::([A-Za-z0-9_]+)", name)
+    return m.group(1) if m else None
 
 
 stats = glob.glob(f"{src}/trace/*/*_kernel_stats.csv")
@@ -69,8 +70,9 @@ moving = [v["hbm_bytes_per_launch"] for k, v in traffic["kernels"].items() if k.
 if moving:
     traffic["scatter_pass_hbm_bytes_per_launch"] = sum(moving) / len(moving)   # mean over the scatter launches that moved keys (bench.py: roofline.traffic)
     traffic["scatter_launches_that_moved_keys"] = len(moving)
-    traffic["algorithmic_bytes_per_launch"] = 8_000_000_000
-    json.dump(traffic, open("profiles/pmc_traffic.json", "w"), indent=1)
+    traffic["algorithmic_bytes_per_launch"] = 8_000_000_000 if levels == 4 else 16_000_000_000
+    if levels == 4 and "f32" not in tag and "u64" not in tag:   # the headline u32 command: what bench.py's roofline.traffic cites
+        json.dump(traffic, open("profiles/pmc_traffic.json", "w"), indent=1)
     json.dump(traffic, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
     print(json.dumps(traffic, indent=1))
 
