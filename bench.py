@@ -214,7 +214,14 @@ def other_inputs(torch, n):
     def reverse():
         return torch.arange(n - 1, -1, -1, dtype=torch.int32, device="cuda")
 
-    return {"u32_bimodal_shift16": ("u32", bimodal), "f32_normal": ("f32", normal), "u32_reverse_arange": ("u32", reverse)}
+    def sum4():   # a smooth bell over the whole range: most keys in 16-bit prefixes of one to four K4 tiles
+        acc = torch.zeros(n, dtype=torch.int64, device="cuda")
+        for i in range(4):
+            acc += gen_keys(torch, n, "u32", 0x5D570010 + i).to(torch.int64) & 0xFFFFFFFF
+        return (acc >> 2).to(torch.int32)   # (wraps: the bit pattern is what counts)
+
+    return {"u32_bimodal_shift16": ("u32", bimodal), "f32_normal": ("f32", normal), "u32_reverse_arange": ("u32", reverse),
+            "u32_sum_of_4_uniforms": ("u32", sum4)}
 
 
 def exact_against_torch_sort(torch, src, out, name):
@@ -449,7 +456,8 @@ def main():
             sh = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
             ceil = {}
             for what, call, moved in (("copy", lambda: lib.rdst_hip_stream_copy(ctypes.c_void_p(b.data_ptr()), ctypes.c_void_p(a.data_ptr()), nbytes, sh), 2 * nbytes),
-                                      ("read", lambda: lib.rdst_hip_stream_read(ctypes.c_void_p(a.data_ptr()), nbytes, sh), nbytes)):
+                                      ("read", lambda: lib.rdst_hip_stream_read(ctypes.c_void_p(a.data_ptr()), nbytes, sh), nbytes),
+                                      ("write", lambda: lib.rdst_hip_stream_fill(ctypes.c_void_p(b.data_ptr()), nbytes, sh), nbytes)):
                 for _ in range(2):
                     _lib.check(call())
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -461,7 +469,8 @@ def main():
                 cms = e0.elapsed_time(e1) / 10
                 ceil[what] = {"ms": round(cms, 4), "GBps": round(moved / (cms * 1e-3) / 1e9, 1),
                               "frac_of_spec": round(moved / (cms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
-            ceil["what"] = f"16-bytes-per-lane streaming kernels over the same {kb * n / 1e9:.1f} GB array, mean of 10 launches each"
+            ceil["what"] = (f"16-bytes-per-lane streaming kernels over the same {kb * n / 1e9:.1f} GB array (one contiguous piece per block, non-temporal "
+                            "loads: the fastest shapes of profiles/r03_copy_sweep.json), mean of 10 launches each")
             line["copy_ceiling"] = ceil
         del bufs, tmp, out
         torch.cuda.empty_cache()

@@ -169,10 +169,12 @@ int rdst_hip_sort_pairs_device(void* dev_keys, void* dev_vals, void* dev_tmp_key
  * later sorts were enqueued, once; the check clears it. */
 int rdst_hip_device_status(void* stream);
 
-/* Bench yardsticks ("a device copy/triad ceiling on the box", beside the 8 TB/s spec): a plain
- * 16-bytes-per-lane streaming copy, and a read-only sweep, of `bytes` (multiple of 16) on `stream`. */
+/* Bench yardsticks ("a device copy/triad ceiling on the box", beside the 8 TB/s spec): a
+ * 16-bytes-per-lane streaming copy, a read-only sweep and a write-only fill of `bytes` (multiple of 16) on `stream`, in the
+ * fastest shape the sweep of profiles/r03_copy_sweep.json found (one contiguous piece per block, non-temporal loads). */
 int rdst_hip_stream_copy(void* dev_dst, const void* dev_src, uint64_t bytes, void* stream);
 int rdst_hip_stream_read(const void* dev_src, uint64_t bytes, void* stream);
+int rdst_hip_stream_fill(void* dev_dst, uint64_t bytes, void* stream);
 
 /* Test hook: ORs `bits` into the device error word from a one-thread kernel on `stream`, exactly as a failing
  * sort kernel would.  The word is sticky: it survives later sorts and workspace growth until

@@ -46,6 +46,7 @@ SYMBOLS = (
     "rdst_hip_debug_raise_device_error",
     "rdst_hip_stream_copy",
     "rdst_hip_stream_read",
+    "rdst_hip_stream_fill",
     "rdst_hip_last_error",
     "rdst_hip_abi_version",
 )
@@ -119,6 +120,7 @@ def load():
     lib.rdst_hip_debug_raise_device_error.argtypes = [u32, vp]
     lib.rdst_hip_stream_copy.argtypes = [vp, vp, u64, vp]
     lib.rdst_hip_stream_read.argtypes = [vp, u64, vp]
+    lib.rdst_hip_stream_fill.argtypes = [vp, u64, vp]
     lib.rdst_hip_last_error.restype = ctypes.c_char_p
     for name in SYMBOLS:
         if name not in ("rdst_hip_workspace_bytes", "rdst_hip_last_error"):

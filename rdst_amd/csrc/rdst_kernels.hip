@@ -1158,7 +1158,16 @@ __global__ __launch_bounds__(256 * SCAN_GROUPS) void scan_kernel(ScanArgs a) {
 #ifdef RDST_EXPERIMENTS
 __device__ uint32_t* g_exp_stats = nullptr;  // [tiles][4] look-back records of pass 0 (tools/ only)
 __device__ uint32_t* g_exp_timeline = nullptr;  // [tiles][12] shader-clock stamps of thread 0 along a tile of pass 0
+__device__ uint32_t g_exp_timeline_kernel = 0;  // whose stamps: 0 K3 (level 0), 1 local_wide2_sort_kernel, 2 / 3 msd_scatter_kernel pass A / B, 4 local_count_sort_kernel
 #define RDST_STAMP(k) do { if (tl_on) tl[k] = (uint32_t)__builtin_amdgcn_s_memtime(); } while (0)
+// the same for the other kernels: RDST_TL_BEGIN(which) declares the record, RDST_TL_END(row) stores it (slots 10, 11: XCC id, block)
+#define RDST_TL_BEGIN(which) uint32_t tl[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; const bool tl_on = g_exp_timeline != nullptr && g_exp_timeline_kernel == (which) && threadIdx.x == 0; RDST_STAMP(0)
+#define RDST_TL_END(row) do { if (tl_on) { uint32_t* rec_ = g_exp_timeline + (size_t)(row) * 12; for (int k_ = 0; k_ < 10; ++k_) rec_[k_] = tl[k_]; \
+    rec_[10] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)); rec_[11] = blockIdx.x; } } while (0)
+#else
+#define RDST_STAMP(k) do {} while (0)
+#define RDST_TL_BEGIN(which) do {} while (0)
+#define RDST_TL_END(row) do {} while (0)
 #endif
 
 // lanes below me holding my digit, 4 VALU per bit: my bit as a 0 / -1 mask (v_bfe_i32), the
@@ -1309,11 +1318,10 @@ __global__ __launch_bounds__(NWAVES * 64, (blocks_per_cu(NWAVES, NARROW ? 4 : 8,
 #define RDST_ABL(bit) (((ablate) >> (bit)) & 1u)
 #else
 #define RDST_ABL(bit) false
-#define RDST_STAMP(k) do {} while (0)
 #endif
 #ifdef RDST_EXPERIMENTS
     uint32_t tl[12];
-    const bool tl_on = g_exp_timeline != nullptr && level == 0 && threadIdx.x == 0;
+    const bool tl_on = g_exp_timeline != nullptr && g_exp_timeline_kernel == 0 && level == 0 && threadIdx.x == 0;
     RDST_STAMP(0);
 #endif
     constexpr int BLOCK = NWAVES * 64;
@@ -1863,7 +1871,11 @@ __global__ __launch_bounds__(NWAVES * 64, RDST_MSD_MINWAVES) void msd_scatter_ke
         // ... or an earlier tile did (a coherent load: the flag is raised by blocks on other XCDs WHILE this kernel runs, so two
         // waves of one block can see different values — the exit must be the block's, not the wave's: a wave that left alone
         // would leave its stale wave_hist table to be summed into the claims of the waves that stayed)
+#ifdef RDST_MSD_WAVE_EXIT  // (tools build, A/B only: round 2's per-wave exit, unsafe with the knob set_hybrid(..., min_len) lowered)
+        if (ld_relaxed<uint32_t>(overflow)) return;
+#else
         if (__syncthreads_or((int)ld_relaxed<uint32_t>(overflow))) return;
+#endif
     }
     const int win = exact ? 0 : (int)plan->win_shift;  // the buckets' 16 bits start this far below the key's top (presample_kernel)
     shift -= win;
@@ -1913,6 +1925,7 @@ __global__ __launch_bounds__(NWAVES * 64, RDST_MSD_MINWAVES) void msd_scatter_ke
     const uint32_t valid = acount - tile_off < (uint64_t)TILE ? (uint32_t)(acount - tile_off) : (uint32_t)TILE;
     const bool full = valid == (uint32_t)TILE;
     const K* tsrc = asrc + tile_off;
+    RDST_TL_BEGIN(SECOND ? 3u : 2u);
     __builtin_amdgcn_s_setprio(RDST_PRIO_LOAD);
     K mk[KPT];
     const uint32_t wbase = (uint32_t)wave * 64u * KPT + (uint32_t)lane;
@@ -1962,6 +1975,7 @@ __global__ __launch_bounds__(NWAVES * 64, RDST_MSD_MINWAVES) void msd_scatter_ke
             if (__builtin_amdgcn_ballot_w64(stray) != 0 && lane == 0 && ld_relaxed<uint32_t>(overflow) == 0) atomicOr(overflow, 1u);
         }
     }
+    RDST_STAMP(1);
     __builtin_amdgcn_s_setprio(0);
     uint32_t* wh = wave_hist + wave * RADIX;
 #pragma unroll
@@ -2042,7 +2056,9 @@ __global__ __launch_bounds__(NWAVES * 64, RDST_MSD_MINWAVES) void msd_scatter_ke
             for (int i = 0; i < KPT; ++i) atomicAdd(&wh[digit_of(mk[i], shift)], 1u);
         }
     }
+    RDST_STAMP(2);
     __syncthreads();
+    RDST_STAMP(3);
     if (tid < RADIX) __builtin_amdgcn_s_setprio(RDST_PRIO_SCAN);
     uint32_t cw[NWAVES];
     uint32_t count_d = 0, pub = 0;
@@ -2092,7 +2108,9 @@ __global__ __launch_bounds__(NWAVES * 64, RDST_MSD_MINWAVES) void msd_scatter_ke
         // (exact form: the counter started at the digit's / bucket's place in the destination — `got` is an element index)
         s_delta[tid] = (exact ? 0u : where * dst_cap) + got - local_off;  // (mod 2^32; the destination arrays hold fewer than 2^32 elements)
     }
+    RDST_STAMP(4);
     __syncthreads();
+    RDST_STAMP(5);
     __builtin_amdgcn_s_setprio(0);
     if (fast) {
 #pragma unroll
@@ -2130,7 +2148,9 @@ __global__ __launch_bounds__(NWAVES * 64, RDST_MSD_MINWAVES) void msd_scatter_ke
             *reinterpret_cast<K*>(reinterpret_cast<unsigned char*>(s_keys) + b + below * SLOT_UNIT) = mk[i];
         }
     }
+    RDST_STAMP(6);
     __syncthreads();
+    RDST_STAMP(7);
     if (s_misc[1]) return;
     __builtin_amdgcn_s_setprio(RDST_PRIO_SCATTER);
     constexpr int SUB = KPT % 6 == 0 ? 6 : (KPT % 4 == 0 ? 4 : (KPT < 6 ? KPT : 6));
@@ -2155,6 +2175,8 @@ __global__ __launch_bounds__(NWAVES * 64, RDST_MSD_MINWAVES) void msd_scatter_ke
             }
         }
     }
+    RDST_STAMP(8);
+    RDST_TL_END(blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -3404,6 +3426,7 @@ __global__ __launch_bounds__(WIDE2_THREADS, 8) void local_wide2_sort_kernel(
     uint16_t* mid16 = reinterpret_cast<uint16_t*>(smem + 32768 + 8192);              // [TILE] bits [16, 32) of the keys at their slots
     uint64_t* out64 = reinterpret_cast<uint64_t*>(smem);                             // [HALF] output staging (everything above is dead by then)
     uint32_t* s_wsum = reinterpret_cast<uint32_t*>(smem + 32768 + 8192 + 2 * TILE);  // [8] wave sums, [16] overflow / ambiguity flag
+    RDST_TL_BEGIN(1);
     __builtin_amdgcn_s_setprio(RDST_PRIO_LOAD);
     const uint64_t* tsrc = src_slots ? src_slots + (uint64_t)bucket * slot_cap : buf + start;
     uint64_t mk[MAXR];
@@ -3415,7 +3438,9 @@ __global__ __launch_bounds__(WIDE2_THREADS, 8) void local_wide2_sort_kernel(
 #pragma unroll
     for (int k = 0; k < WPT; ++k) cnt4[k * BLOCK + tid] = 0;
     if (tid == 0) s_wsum[16] = 0;
+    RDST_STAMP(1);
     __syncthreads();
+    RDST_STAMP(2);
     __builtin_amdgcn_s_setprio(0);
     auto word_of = [](uint32_t v) -> uint32_t { return ((v >> 3) & (uint32_t)(WPT - 1)) * BLOCK + (v >> LOG_VPT); };
     constexpr uint64_t LOW48 = (1ull << 48) - 1;  // per-key state rides in the key's top 16 bits (the bucket index, restored at the end)
@@ -3434,6 +3459,7 @@ __global__ __launch_bounds__(WIDE2_THREADS, 8) void local_wide2_sort_kernel(
         }
     }
     if (flag) s_wsum[16] = 1;
+    RDST_STAMP(3);
     __syncthreads();
     if (s_wsum[16]) {  // block-uniform: the bucket stays as it is, for the generic kernel
         if (tid == 0) list[atomicAdd(list_count, 1u)] = bucket;
@@ -3463,6 +3489,7 @@ __global__ __launch_bounds__(WIDE2_THREADS, 8) void local_wide2_sort_kernel(
         for (int k = 0; k < WPT / 2; ++k) prefix2[k * BLOCK + tid] = (uint16_t)(base + pre[k]);
     }
     __syncthreads();
+    RDST_STAMP(4);
     // first slot of a value: the pair's prefix, the even word's nibbles if the value sits in the odd word, the nibbles below it
     auto first_slot = [&](uint32_t v, uint32_t w, uint32_t wd) -> uint32_t {
         const uint32_t k = (v >> 3) & (uint32_t)(WPT - 1);
@@ -3481,6 +3508,7 @@ __global__ __launch_bounds__(WIDE2_THREADS, 8) void local_wide2_sort_kernel(
             mk[i] = (mk[i] & LOW48) | ((uint64_t)slot << 48);
         }
     }
+    RDST_STAMP(5);
     __syncthreads();
     // ties: my place inside my group = members with smaller bits [16, 32) (equal ones would need the low 16 bits: give up)
 #pragma unroll
@@ -3505,6 +3533,7 @@ __global__ __launch_bounds__(WIDE2_THREADS, 8) void local_wide2_sort_kernel(
         }
     }
     if (flag) s_wsum[16] = 1;
+    RDST_STAMP(6);
     __syncthreads();  // every look at the tables and the staged bits is done: their space becomes the output staging
     if (s_wsum[16]) {
         if (tid == 0) list[atomicAdd(list_count, 1u)] = bucket;
@@ -3522,6 +3551,7 @@ __global__ __launch_bounds__(WIDE2_THREADS, 8) void local_wide2_sort_kernel(
             if (idx < cnt && rel < (uint32_t)HALF) out64[rel] = (mk[i] & LOW48) | ((uint64_t)bucket_prefix16(plan, bucket) << 48);
         }
         __syncthreads();
+        if (h == 0) RDST_STAMP(7);
         __builtin_amdgcn_s_setprio(RDST_PRIO_SCATTER);
 #pragma unroll
         for (int i = 0; i < HALF / BLOCK; ++i) {
@@ -3529,7 +3559,10 @@ __global__ __launch_bounds__(WIDE2_THREADS, 8) void local_wide2_sort_kernel(
             if (at < cnt) tdst[at] = MAPPED ? unmap_key<uint64_t>(out64[rel], neg, pos) : out64[rel];
         }
         if (h == 0) __syncthreads();  // the second half reuses the staging
+        if (h == 0) RDST_STAMP(8);
     }
+    RDST_STAMP(9);
+    RDST_TL_END(bucket);
 }
 
 // result sits in tmp after an odd number of executed passes: copy back
@@ -3594,33 +3627,35 @@ __global__ __launch_bounds__(256) void gather_records_kernel(const UNIT* __restr
     }
 }
 
-// Streaming yardsticks for the bench (rdst_hip_stream_copy / rdst_hip_stream_read): 16 bytes per lane, four
-// vectors in flight, grid-stride — what this HBM delivers to the simplest kernel there is, beside the 8 TB/s spec.
-__global__ __launch_bounds__(256) void stream_copy_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, uint64_t nvec) {
-    const uint64_t stride = (uint64_t)gridDim.x * 256;
-    uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 3 * stride < nvec; i += 4 * stride) {
-        uint4 v[4];
+// Streaming yardsticks for the bench (rdst_hip_stream_copy / _read / _fill): what this HBM delivers to the simplest kernels
+// there are, beside the 8 TB/s spec.  The shape is the fastest of tools/probe/copy_sweep.hip's sweep (profiles/r03_copy_sweep.json):
+// 16 bytes per lane, ONE CONTIGUOUS PIECE PER BLOCK (a grid-stride sweep loses 10-15 % to first-level TLB misses: every 4 KiB step
+// of a block lands in another 2 MiB fragment), eight vectors in flight, non-temporal loads (reads: 7.0 instead of 6.1 TB/s).
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+template <int MODE /* 0 copy, 1 read, 2 fill */>
+__global__ __launch_bounds__(256) void stream_kernel(u32x4_t* __restrict__ dst, const u32x4_t* __restrict__ src, uint64_t nvec, uint32_t* __restrict__ sink) {
+    constexpr int U = 8;
+    const uint64_t piece = ((nvec + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
+    uint64_t i = (uint64_t)blockIdx.x * piece + threadIdx.x;
+    const uint64_t end = (uint64_t)(blockIdx.x + 1) * piece < nvec ? (uint64_t)(blockIdx.x + 1) * piece : nvec;
+    u32x4_t acc = {0, 0, 0, 0};
+    for (; i + (U - 1) * 256 < end; i += U * 256) {
+        u32x4_t v[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = src[i + u * stride];
+        for (int u = 0; u < U; ++u) v[u] = MODE == 2 ? (u32x4_t){(uint32_t)i, 1u, 2u, 3u} : __builtin_nontemporal_load(src + i + u * 256);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) dst[i + u * stride] = v[u];
+        for (int u = 0; u < U; ++u) {
+            if (MODE == 0) __builtin_nontemporal_store(v[u], dst + i + u * 256);
+            else if (MODE == 2) dst[i + u * 256] = v[u];
+            else acc ^= v[u];
+        }
     }
-    for (; i < nvec; i += stride) dst[i] = src[i];
-}
-__global__ __launch_bounds__(256) void stream_read_kernel(const uint4* __restrict__ src, uint64_t nvec, uint32_t* __restrict__ sink) {
-    const uint64_t stride = (uint64_t)gridDim.x * 256;
-    uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    uint32_t acc = 0;
-    for (; i + 3 * stride < nvec; i += 4 * stride) {
-        uint4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = src[i + u * stride];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+    for (; i < end; i += 256) {
+        const u32x4_t v = MODE == 2 ? (u32x4_t){(uint32_t)i, 1u, 2u, 3u} : __builtin_nontemporal_load(src + i);
+        if (MODE == 1) acc ^= v;
+        else dst[i] = v;
     }
-    for (; i < nvec; i += stride) acc ^= src[i].x ^ src[i].w;
-    if (acc == 0x9E3779B9u) *sink = acc;  // keeps the loads alive; practically never taken
+    if (MODE == 1 && (acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9E3779B9u) *sink = acc.x;  // keeps the loads alive; practically never taken
 }
 
 // Status rows of the levels only the LSD route uses: cleared after the route decision, and only if it fell that way
@@ -3903,7 +3938,10 @@ Layout make_layout(uint64_t n, uint32_t elem_bytes, uint32_t levels, int cfg, ui
         const uint64_t tiles = (n + TILE - 1) / TILE;
         L.msd_slices = tiles >= 64 * MSD_SLICES ? MSD_SLICES : 1;
         const double mean = (double)n / (RADIX * L.msd_slices);
-        const double slack = mean * 0.125 > 8.0 * __builtin_sqrt(mean) ? mean * 0.125 : 8.0 * __builtin_sqrt(mean);
+#ifndef RDST_AREA_SLACK
+#define RDST_AREA_SLACK 0.125
+#endif
+        const double slack = mean * RDST_AREA_SLACK > 8.0 * __builtin_sqrt(mean) ? mean * RDST_AREA_SLACK : 8.0 * __builtin_sqrt(mean);
         L.msd_cap_a = (uint32_t)(((uint64_t)(mean + slack) + 2 * TILE / RADIX + 64) / 64 * 64);
         o += align_up((size_t)elem_bytes * L.msd_cap_a * RADIX * L.msd_slices, 256);
     }
@@ -4956,8 +4994,8 @@ int rdst_hip_stream_copy(void* dev_dst, const void* dev_src, uint64_t bytes, voi
     DeviceState* D;
     int rc = current_device_state(&D);
     if (rc) return rc;
-    hipLaunchKernelGGL(stream_copy_kernel, dim3((uint32_t)D->cus * 8), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<uint4*>(dev_dst),
-                       static_cast<const uint4*>(dev_src), bytes / 16);
+    hipLaunchKernelGGL((stream_kernel<0>), dim3((uint32_t)D->cus * 8), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<u32x4_t*>(dev_dst),
+                       static_cast<const u32x4_t*>(dev_src), bytes / 16, D->err_dev + 8);
     HIP_TRY(hipGetLastError());
     return RDST_OK;
 }
@@ -4969,8 +5007,21 @@ int rdst_hip_stream_read(const void* dev_src, uint64_t bytes, void* stream) {
     DeviceState* D;
     int rc = current_device_state(&D);
     if (rc) return rc;
-    hipLaunchKernelGGL(stream_read_kernel, dim3((uint32_t)D->cus * 8), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const uint4*>(dev_src),
-                       bytes / 16, D->err_dev + 8);
+    hipLaunchKernelGGL((stream_kernel<1>), dim3((uint32_t)D->cus * 8), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<u32x4_t*>(nullptr),
+                       static_cast<const u32x4_t*>(dev_src), bytes / 16, D->err_dev + 8);
+    HIP_TRY(hipGetLastError());
+    return RDST_OK;
+}
+
+int rdst_hip_stream_fill(void* dev_dst, uint64_t bytes, void* stream) {
+    if (!dev_dst) return fail(RDST_ERR_ARG, "null pointer");
+    if ((reinterpret_cast<uintptr_t>(dev_dst) | bytes) & 15u) return fail(RDST_ERR_ALIGN, "16-byte alignment");
+    std::lock_guard<std::mutex> lock(g_mutex);
+    DeviceState* D;
+    int rc = current_device_state(&D);
+    if (rc) return rc;
+    hipLaunchKernelGGL((stream_kernel<2>), dim3((uint32_t)D->cus * 8), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<u32x4_t*>(dev_dst),
+                       static_cast<const u32x4_t*>(nullptr), bytes / 16, D->err_dev + 8);
     HIP_TRY(hipGetLastError());
     return RDST_OK;
 }
@@ -5011,6 +5062,9 @@ int rdst_hip_exp_timeline(uint32_t* host_out, uint64_t tiles) {
     uint32_t* null_dev = nullptr;
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_exp_timeline), &null_dev, sizeof null_dev);
     return hipMemcpy(host_out, dev, tiles * 48, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+int rdst_hip_exp_timeline_select(uint32_t which) {  // 0 K3 level 0, 1 local_wide2_sort_kernel, 2 / 3 msd_scatter_kernel pass A / B
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_exp_timeline_kernel), &which, sizeof which) == hipSuccess ? 0 : -1;
 }
 int rdst_hip_exp_stats(uint32_t* host_out, uint64_t tiles) {
     static uint32_t* dev = nullptr;

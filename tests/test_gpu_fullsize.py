@@ -193,8 +193,10 @@ def test_eight_billion_u64_keys_on_one_gpu(gpu):
     source is not kept (keys + tmp + workspace ~ 155 GB)."""
     import torch
     n = 8_000_000_000
+    torch.cuda.empty_cache()          # (earlier tests' blocks sit in torch's caching allocator)
+    gpu.release_workspace()           # ... and the 10^9-key routes' 7-19 GB workspace in the library
     free, _ = torch.cuda.mem_get_info()
-    assert free > 170 * 2**30, f"needs ~170 GiB of free HBM, {free / 2**30:.0f} available"
+    assert free > 150 * 2**30, f"needs ~150 GiB of free HBM (64 + 64 + 24 GB), {free / 2**30:.0f} available"
     keys = _gen(torch, n, torch.int64, 0x5D570005)
     view = keys.view(torch.uint64)
     before = gpu.all_level_counts(view)
@@ -221,6 +223,8 @@ def test_more_than_2_pow_32_u32_keys(gpu):
     """4-byte keys past 2^32 ELEMENTS (17 GB + 17 GB): 64-bit destinations in every pass, tile starts past 2^32."""
     import torch
     n = (1 << 32) + 54_321
+    torch.cuda.empty_cache()
+    gpu.release_workspace()
     keys = _gen(torch, n, torch.int32, 0x5D57000C)
     view = keys.view(torch.uint32)
     before = gpu.all_level_counts(view)
