@@ -19,11 +19,23 @@ def _hipcc():
     raise RuntimeError("hipcc not found; the device route cannot be built (there is no CPU fallback)")
 
 
+STAMP = OUT + ".srchash"   # what the library was built from (content, not mtimes: a checkout or a snapshot copy changes those)
+
+
+def _source_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for p in SOURCES + HEADERS:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def needs_build():
-    if not os.path.exists(OUT):
+    if not os.path.exists(OUT) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(p) > t for p in SOURCES + HEADERS)
+    with open(STAMP) as f:
+        return f.read().strip() != _source_hash()
 
 
 def build(force=False, verbose=False):
@@ -34,6 +46,8 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
+    with open(STAMP, "w") as f:
+        f.write(_source_hash() + "\n")
     return OUT
 
 

@@ -1871,12 +1871,19 @@ __global__ __launch_bounds__(NWAVES * 64, RDST_MSD_MINWAVES) void msd_scatter_ke
         // ... or an earlier tile did (a coherent load: the flag is raised by blocks on other XCDs WHILE this kernel runs, so two
         // waves of one block can see different values — the exit must be the block's, not the wave's: a wave that left alone
         // would leave its stale wave_hist table to be summed into the claims of the waves that stayed)
+#ifndef RDST_MSD_EXIT
+#define RDST_MSD_EXIT 0  // 0: decided at the top of the kernel; 2: the flag is requested at the top and looked at behind the tile's loads, at the first barrier the kernel has anyway
+#endif
 #ifdef RDST_MSD_WAVE_EXIT  // (tools build, A/B only: round 2's per-wave exit, unsafe with the knob set_hybrid(..., min_len) lowered)
         if (ld_relaxed<uint32_t>(overflow)) return;
-#else
+#elif RDST_MSD_EXIT == 0
         if (__syncthreads_or((int)ld_relaxed<uint32_t>(overflow))) return;
 #endif
     }
+    uint32_t gave_up = 0;
+#if RDST_MSD_EXIT == 2 && !defined(RDST_MSD_WAVE_EXIT)
+    if (!exact) gave_up = ld_relaxed<uint32_t>(overflow);
+#endif
     const int win = exact ? 0 : (int)plan->win_shift;  // the buckets' 16 bits start this far below the key's top (presample_kernel)
     shift -= win;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -2057,7 +2064,22 @@ __global__ __launch_bounds__(NWAVES * 64, RDST_MSD_MINWAVES) void msd_scatter_ke
         }
     }
     RDST_STAMP(2);
+#if RDST_MSD_EXIT == 2 && !defined(RDST_MSD_WAVE_EXIT)
+    // block-uniform without a barrier of its own (__syncthreads_or is a software reduction: two barriers and LDS traffic): every
+    // wave leaves what it saw in its own word before the barrier the kernel has anyway, every thread reads all the words behind it
+    static_assert(NWAVES <= 16, "one word of s_misc per wave");
+    if (lane == 0) s_misc[16 + wave] = gave_up;
     __syncthreads();
+    {
+        uint32_t any = 0;
+#pragma unroll
+        for (int w = 0; w < NWAVES; ++w) any |= s_misc[16 + w];
+        if (any) return;  // the flag's latency hid behind the tile's loads
+    }
+#else
+    (void)gave_up;
+    __syncthreads();
+#endif
     RDST_STAMP(3);
     if (tid < RADIX) __builtin_amdgcn_s_setprio(RDST_PRIO_SCAN);
     uint32_t cw[NWAVES];
@@ -2505,8 +2527,9 @@ template <typename K, int NWAVES, int KPT, bool MAPPED>
 __global__ __launch_bounds__(NWAVES * 64, (sizeof(K) <= 4 ? 2 : 1) * NWAVES / 4) void local_sort_kernel(
     K* __restrict__ buf_keys, K* __restrict__ buf_tmp, const uint32_t* __restrict__ bstart, const Plan* __restrict__ plan,
     uint32_t* __restrict__ err, K neg, K pos, uint32_t flags, const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count,
-    const uint16_t* __restrict__ src16, const uint32_t* __restrict__ slot_count, uint32_t slot_cap, const K* __restrict__ alt_src) {
-    if (!plan->local_sort) return;
+    const uint16_t* __restrict__ src16, const uint32_t* __restrict__ slot_count, uint32_t slot_cap, const K* __restrict__ alt_src,
+    uint32_t only_route /* 0, or ROUTE_x + 1: this launch serves that route only (the fallback routes' launches run on a side stream) */) {
+    if (!plan->local_sort || (only_route && plan->route + 1u != only_route)) return;
     if (plan->route != ROUTE_ATOMIC) { slot_count = nullptr; alt_src = nullptr; }  // the hybrid route's buckets lie at their final place
     K* __restrict__ buf = plan->result_in_tmp ? buf_tmp : buf_keys;
     if (list == nullptr) {
@@ -2555,12 +2578,13 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 8 : 6) void local_count_sort
     uint32_t* __restrict__ buf_keys, uint32_t* __restrict__ buf_tmp, const uint16_t* __restrict__ src16, const uint32_t* __restrict__ bstart,
     const Plan* __restrict__ plan, uint32_t* __restrict__ err, uint32_t neg, uint32_t pos, uint32_t* __restrict__ list,
     uint32_t* __restrict__ list_count, const uint32_t* __restrict__ slot_count /* ROUTE_ATOMIC: bucket b's halves lie in slot b (slot_cap
-    entries) of src16 and number slot_count[b]; NULL: they lie at their final place, bstart */, uint32_t slot_cap) {
+    entries) of src16 and number slot_count[b]; NULL: they lie at their final place, bstart */, uint32_t slot_cap,
+    uint32_t only_route /* 0, or ROUTE_x + 1: this launch serves that route only (the fallback routes' launches run on a side stream) */) {
     constexpr int MAXR = (COUNT_TILE + BLOCK - 1) / BLOCK;
     constexpr int VPT = H16_BINS / BLOCK, WPT = VPT / 8;  // values / counter words per thread
     constexpr int LOG_VPT = BLOCK == 1024 ? 6 : (BLOCK == 512 ? 7 : 8);
     static_assert((1 << LOG_VPT) == VPT, "block size");
-    if (!plan->local_sort) return;
+    if (!plan->local_sort || (only_route && plan->route + 1u != only_route)) return;
     if (plan->route != ROUTE_ATOMIC) slot_count = nullptr;  // the hybrid route's buckets lie at their final place (src16: position for position)
     uint32_t* __restrict__ buf = plan->result_in_tmp ? buf_tmp : buf_keys;
     const uint32_t bucket = blockIdx.x;
@@ -2718,9 +2742,10 @@ template <bool MAPPED, bool FROM16>
 __global__ __launch_bounds__(EXPAND_THREADS) void local_expand_sort_kernel(
     uint32_t* __restrict__ buf_keys, uint32_t* __restrict__ buf_tmp, const uint16_t* __restrict__ src16, const uint32_t* __restrict__ bstart,
     const Plan* __restrict__ plan, uint32_t* __restrict__ err, uint32_t neg, uint32_t pos, const uint32_t* __restrict__ list,
-    const uint32_t* __restrict__ list_count, const uint32_t* __restrict__ slot_count, uint32_t slot_cap) {
+    const uint32_t* __restrict__ list_count, const uint32_t* __restrict__ slot_count, uint32_t slot_cap,
+    uint32_t only_route /* 0, or ROUTE_x + 1: this launch serves that route only (the fallback routes' launches run on a side stream) */) {
     constexpr int BLOCK = EXPAND_THREADS, WPT = H16_BINS / 2 / BLOCK;  // 32 words of two counters per thread
-    if (!plan->local_sort) return;
+    if (!plan->local_sort || (only_route && plan->route + 1u != only_route)) return;
     if (plan->route != ROUTE_ATOMIC) slot_count = nullptr;
     uint32_t* __restrict__ buf = plan->result_in_tmp ? buf_tmp : buf_keys;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -2834,9 +2859,10 @@ template <bool MAPPED, bool FROM16>
 __global__ __launch_bounds__(COUNT16_THREADS) void local_count16_sort_kernel(
     uint32_t* __restrict__ buf_keys, uint32_t* __restrict__ buf_tmp, const uint16_t* __restrict__ src16, const uint32_t* __restrict__ bstart,
     const Plan* __restrict__ plan, uint32_t neg, uint32_t pos, const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count,
-    uint32_t* __restrict__ list2, uint32_t* __restrict__ list2_count, const uint32_t* __restrict__ slot_count, uint32_t slot_cap) {
+    uint32_t* __restrict__ list2, uint32_t* __restrict__ list2_count, const uint32_t* __restrict__ slot_count, uint32_t slot_cap,
+    uint32_t only_route /* 0, or ROUTE_x + 1: this launch serves that route only (the fallback routes' launches run on a side stream) */) {
     constexpr int BLOCK = COUNT16_THREADS, KPT = COUNT16_KPT, WPT = H16_BINS / 2 / BLOCK;
-    if (!plan->local_sort) return;
+    if (!plan->local_sort || (only_route && plan->route + 1u != only_route)) return;
     if (plan->route != ROUTE_ATOMIC) slot_count = nullptr;
     uint32_t* __restrict__ buf = plan->result_in_tmp ? buf_tmp : buf_keys;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -3251,10 +3277,11 @@ static_assert(WIDE_TILE % (2 * WIDE_THREADS) == 0, "two output halves of whole r
 template <bool MAPPED>
 __global__ __launch_bounds__(WIDE_THREADS, 4) void local_wide_sort_kernel(
     uint64_t* __restrict__ buf_keys, uint64_t* __restrict__ buf_tmp, const uint32_t* __restrict__ bstart, const Plan* __restrict__ plan,
-    uint32_t* __restrict__ err, uint64_t neg, uint64_t pos, uint32_t* __restrict__ list, uint32_t* __restrict__ list_count) {
+    uint32_t* __restrict__ err, uint64_t neg, uint64_t pos, uint32_t* __restrict__ list, uint32_t* __restrict__ list_count,
+    uint32_t only_route /* 0, or ROUTE_x + 1: this launch serves that route only (the fallback routes' launches run on a side stream) */) {
     constexpr int BLOCK = WIDE_THREADS, MAXR = WIDE_TILE / BLOCK, WPT = H16_BINS / BLOCK / 8, LOG_VPT = 6;
     constexpr int HALF = WIDE_TILE / 2;
-    if (!plan->local_sort) return;
+    if (!plan->local_sort || (only_route && plan->route + 1u != only_route)) return;
     uint64_t* __restrict__ buf = plan->result_in_tmp ? buf_tmp : buf_keys;
     const uint32_t bucket = blockIdx.x;
     const uint32_t start = bstart[bucket], cnt = bstart[bucket + 1] - start;
@@ -3404,12 +3431,13 @@ __global__ __launch_bounds__(WIDE2_THREADS, 8) void local_wide2_sort_kernel(
     uint64_t* __restrict__ buf_keys, uint64_t* __restrict__ buf_tmp, const uint32_t* __restrict__ bstart, const Plan* __restrict__ plan,
     uint32_t* __restrict__ err, uint64_t neg, uint64_t pos, uint32_t* __restrict__ list, uint32_t* __restrict__ list_count,
     const uint64_t* __restrict__ src_slots /* ROUTE_ATOMIC: bucket b's keys lie in slot b (slot_cap keys) and number slot_count[b]; NULL: in place */,
-    const uint32_t* __restrict__ slot_count, uint32_t slot_cap) {
+    const uint32_t* __restrict__ slot_count, uint32_t slot_cap,
+    uint32_t only_route /* 0, or ROUTE_x + 1: this launch serves that route only (the fallback routes' launches run on a side stream) */) {
     constexpr int TILE = local_tile(8);
     constexpr int BLOCK = WIDE2_THREADS, MAXR = TILE / BLOCK, WPT = H16_BINS / BLOCK / 8, LOG_VPT = 6;
     constexpr int HALF = TILE / 2;
     static_assert((size_t)HALF * 8 <= 32768 + 8192 + 2 * (size_t)TILE, "output staging fits the dead tables");
-    if (!plan->local_sort) return;
+    if (!plan->local_sort || (only_route && plan->route + 1u != only_route)) return;
     if (plan->route != ROUTE_ATOMIC) src_slots = nullptr;  // the hybrid route's buckets lie at their final place
     uint64_t* __restrict__ buf = plan->result_in_tmp ? buf_tmp : buf_keys;
     const uint32_t bucket = blockIdx.x;
@@ -3805,6 +3833,7 @@ struct Tuning {
     bool atomic_wide = true;            // ROUTE_ATOMIC for 8-byte keys too (whole keys in the slots)
     bool persist_fallback = true;       // behind the atomic route the LSD passes run as persistent blocks (cheap to skip)
     bool predict = true;                // the sample may predict the LSD route (Plan::predict_lsd): neither MSD passes nor K1h are tried
+    bool side_stream = true;            // behind a tried atomic route the fallback routes' launches go to a side stream (DeviceState::side_stream)
     uint64_t hybrid_min_len = 1ull << 28;  // below this the buckets are too small for one workgroup each to pay off
 };
 uint32_t g_ablate = 0;  // only ever set by the RDST_EXPERIMENTS build
@@ -3830,6 +3859,10 @@ struct DeviceState {
     std::mutex host_mutex;              // one host-slice sort per device at a time (they share stream and buffer)
     hipEvent_t host_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // around H2D, sort, D2H of the most recent host-slice sort
     bool host_timed = false;
+    // The fallback routes' launches behind a tried atomic route run on a stream of the library's own, forked after the route
+    // decision and joined at the end: on the good path their ~20 launches return at once BESIDE K4 instead of before it
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t last_done = nullptr;  // recorded after every enqueue that uses the workspace
     hipStream_t last_stream = nullptr;
     bool have_last = false;
@@ -4017,7 +4050,9 @@ int workspace_release(DeviceState& D, hipStream_t s) {
     return RDST_OK;
 }
 
-// `kind`: the stage that ENDS at this mark (ignored for a run's first mark)
+// `kind`: the stage that ENDS at this mark (ignored for a run's first mark).  RDST_STAGE_NONE: no stage — this mark is the first one
+// on another stream, the interval before it means nothing (rdst_hip_profile_run reports 0 for it)
+constexpr uint32_t RDST_STAGE_NONE = 0xFF;
 int prof_mark(DeviceState& D, hipStream_t s, uint32_t kind = 0) {
     if (!g_tuning.profiling || D.prof_runs.empty() || D.prof_used >= 8192) return RDST_OK;
     if (D.prof_used == D.prof_events.size()) {
@@ -4172,7 +4207,7 @@ template <typename K>
 int launch_local_sort(K* keys, K* tmp, const uint32_t* bstart, const Plan* plan, uint32_t* err, KeyMap km, uint32_t* list,
                       uint32_t* list_count, const uint16_t* src16, int cus, hipStream_t s, const uint32_t* slot_count = nullptr,
                       uint32_t slot_cap = 0, const K* src_slots = nullptr, uint32_t* list2 = nullptr, uint32_t* list2_count = nullptr,
-                      const GiantArgs* ga = nullptr) {
+                      const GiantArgs* ga = nullptr, uint32_t only_route = 0) {
     constexpr int NW = local_waves(sizeof(K)), KPT = local_kpt(sizeof(K));
     constexpr size_t lds = local_lds_bytes(sizeof(K));
     const bool mapped = km.neg != 0 || km.pos != 0;
@@ -4185,7 +4220,7 @@ int launch_local_sort(K* keys, K* tmp, const uint32_t* bstart, const Plan* plan,
     do {                                                                                                                             \
         if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_count_sort_kernel<COUNT_THREADS, MAPPED, FROM16>), clds)) return rc; \
         hipLaunchKernelGGL((local_count_sort_kernel<COUNT_THREADS, MAPPED, FROM16>), dim3(H16_BINS), dim3(COUNT_THREADS), clds, s, keys, tmp, \
-                           src16, bstart, plan, err, (uint32_t)km.neg, (uint32_t)km.pos, list, list_count, slot_count, slot_cap); \
+                           src16, bstart, plan, err, (uint32_t)km.neg, (uint32_t)km.pos, list, list_count, slot_count, slot_cap, only_route); \
     } while (0)
             if (src16) { if (mapped) RDST_COUNT(true, true); else RDST_COUNT(false, true); }
             else { if (mapped) RDST_COUNT(true, false); else RDST_COUNT(false, false); }
@@ -4197,7 +4232,7 @@ int launch_local_sort(K* keys, K* tmp, const uint32_t* bstart, const Plan* plan,
     do {                                                                                                                             \
         if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_count16_sort_kernel<MAPPED, FROM16>), elds)) return rc;    \
         hipLaunchKernelGGL((local_count16_sort_kernel<MAPPED, FROM16>), dim3((uint32_t)cus), dim3(COUNT16_THREADS), elds, s, keys, tmp, \
-                           src16, bstart, plan, (uint32_t)km.neg, (uint32_t)km.pos, list, list_count, list2, list2_count, slot_count, slot_cap); \
+                           src16, bstart, plan, (uint32_t)km.neg, (uint32_t)km.pos, list, list_count, list2, list2_count, slot_count, slot_cap, only_route); \
     } while (0)
                 if (src16) { if (mapped) RDST_COUNT16(true, true); else RDST_COUNT16(false, true); }
                 else { if (mapped) RDST_COUNT16(true, false); else RDST_COUNT16(false, false); }
@@ -4207,7 +4242,7 @@ int launch_local_sort(K* keys, K* tmp, const uint32_t* bstart, const Plan* plan,
     do {                                                                                                                             \
         if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_expand_sort_kernel<MAPPED, FROM16>), elds)) return rc;     \
         hipLaunchKernelGGL((local_expand_sort_kernel<MAPPED, FROM16>), dim3((uint32_t)cus), dim3(EXPAND_THREADS), elds, s, keys, tmp, \
-                           src16, bstart, plan, err, (uint32_t)km.neg, (uint32_t)km.pos, list2, list2_count, slot_count, slot_cap); \
+                           src16, bstart, plan, err, (uint32_t)km.neg, (uint32_t)km.pos, list2, list2_count, slot_count, slot_cap, only_route); \
     } while (0)
                 if (src16) { if (mapped) RDST_EXPAND(true, true); else RDST_EXPAND(false, true); }
                 else { if (mapped) RDST_EXPAND(true, false); else RDST_EXPAND(false, false); }
@@ -4243,17 +4278,17 @@ int launch_local_sort(K* keys, K* tmp, const uint32_t* bstart, const Plan* plan,
                 constexpr size_t w2 = wide2_lds_bytes();
                 if (mapped) {
                     if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_wide2_sort_kernel<true>), w2)) return rc;
-                    hipLaunchKernelGGL((local_wide2_sort_kernel<true>), dim3(H16_BINS), dim3(WIDE2_THREADS), w2, s, keys, tmp, bstart, plan, err, (uint64_t)km.neg, (uint64_t)km.pos, list, list_count, src_slots, slot_count, slot_cap);
+                    hipLaunchKernelGGL((local_wide2_sort_kernel<true>), dim3(H16_BINS), dim3(WIDE2_THREADS), w2, s, keys, tmp, bstart, plan, err, (uint64_t)km.neg, (uint64_t)km.pos, list, list_count, src_slots, slot_count, slot_cap, only_route);
                 } else {
                     if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_wide2_sort_kernel<false>), w2)) return rc;
-                    hipLaunchKernelGGL((local_wide2_sort_kernel<false>), dim3(H16_BINS), dim3(WIDE2_THREADS), w2, s, keys, tmp, bstart, plan, err, (uint64_t)km.neg, (uint64_t)km.pos, list, list_count, src_slots, slot_count, slot_cap);
+                    hipLaunchKernelGGL((local_wide2_sort_kernel<false>), dim3(H16_BINS), dim3(WIDE2_THREADS), w2, s, keys, tmp, bstart, plan, err, (uint64_t)km.neg, (uint64_t)km.pos, list, list_count, src_slots, slot_count, slot_cap, only_route);
                 }
             } else if (mapped) {
                 if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_wide_sort_kernel<true>), wlds)) return rc;
-                hipLaunchKernelGGL((local_wide_sort_kernel<true>), dim3(H16_BINS), dim3(WIDE_THREADS), wlds, s, keys, tmp, bstart, plan, err, (uint64_t)km.neg, (uint64_t)km.pos, list, list_count);
+                hipLaunchKernelGGL((local_wide_sort_kernel<true>), dim3(H16_BINS), dim3(WIDE_THREADS), wlds, s, keys, tmp, bstart, plan, err, (uint64_t)km.neg, (uint64_t)km.pos, list, list_count, only_route);
             } else {
                 if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_wide_sort_kernel<false>), wlds)) return rc;
-                hipLaunchKernelGGL((local_wide_sort_kernel<false>), dim3(H16_BINS), dim3(WIDE_THREADS), wlds, s, keys, tmp, bstart, plan, err, (uint64_t)km.neg, (uint64_t)km.pos, list, list_count);
+                hipLaunchKernelGGL((local_wide_sort_kernel<false>), dim3(H16_BINS), dim3(WIDE_THREADS), wlds, s, keys, tmp, bstart, plan, err, (uint64_t)km.neg, (uint64_t)km.pos, list, list_count, only_route);
             }
             HIP_TRY(hipGetLastError());
             listed = true;
@@ -4263,10 +4298,10 @@ int launch_local_sort(K* keys, K* tmp, const uint32_t* bstart, const Plan* plan,
     const uint32_t* wl = listed ? list : nullptr;
     if (mapped) {
         if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_sort_kernel<K, NW, KPT, true>), lds)) return rc;
-        hipLaunchKernelGGL((local_sort_kernel<K, NW, KPT, true>), grid, dim3(NW * 64), lds, s, keys, tmp, bstart, plan, err, (K)km.neg, (K)km.pos, flags, wl, list_count, src16, slot_count, slot_cap, src_slots);
+        hipLaunchKernelGGL((local_sort_kernel<K, NW, KPT, true>), grid, dim3(NW * 64), lds, s, keys, tmp, bstart, plan, err, (K)km.neg, (K)km.pos, flags, wl, list_count, src16, slot_count, slot_cap, src_slots, only_route);
     } else {
         if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_sort_kernel<K, NW, KPT, false>), lds)) return rc;
-        hipLaunchKernelGGL((local_sort_kernel<K, NW, KPT, false>), grid, dim3(NW * 64), lds, s, keys, tmp, bstart, plan, err, (K)km.neg, (K)km.pos, flags, wl, list_count, src16, slot_count, slot_cap, src_slots);
+        hipLaunchKernelGGL((local_sort_kernel<K, NW, KPT, false>), grid, dim3(NW * 64), lds, s, keys, tmp, bstart, plan, err, (K)km.neg, (K)km.pos, flags, wl, list_count, src16, slot_count, slot_cap, src_slots, only_route);
     }
     HIP_TRY(hipGetLastError());
     return RDST_OK;
@@ -4426,7 +4461,7 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
         r.cfg = cfg0;
         r.try_atomic = !lean && whole_sort && atomic_eligible(n, sizeof(K), r.cfg);
         // 8-byte keys: the fallback's passes run as persistent blocks of shape 5 (eight skipped passes of one block per tile cost 0.5 ms per 10^9 keys)
-        if (r.try_atomic && sizeof(K) == 8 && g_tuning.persist_fallback && g_tuning.pass_cfg < 0) r.cfg = 5;
+        if (r.try_atomic && sizeof(K) == 8 && g_tuning.persist_fallback && !g_tuning.side_stream && g_tuning.pass_cfg < 0) r.cfg = 5;
         // Behind a failed atomic route (an area or a slot overflowed) the hybrid route is tried next — exact counts, any bucket
         // the local sort takes — and the LSD route last.  One launch sequence serves all three: every kernel looks at the plan.
         const bool halves_cfg = g_tuning.halves && g_tuning.count_sort && halves_possible<K>(r.cfg, n);
@@ -4498,16 +4533,18 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     const bool pair = g_tuning.chains && LEVELS >= 2 && level_hi > level_lo + 1;
     unsigned long long* hpair = reinterpret_cast<unsigned long long*>(ws + L.off_hpair);
     Plan* plan = reinterpret_cast<Plan*>(ws + L.off_plan);
+    hipStream_t fs = s;   // the stream the fallback routes' launches go to (the side stream once forked)
+    bool forked = false;
     // K1h + the route decision, launched twice behind a tried atomic route: before the MSD passes (they run only if the sample
     // flagged the keys; the MSD passes then take their exact form for the hybrid route) and after them (what is left)
-    auto count_and_route = [&](uint32_t pre_launch, bool sample_first) -> int {
+    auto count_and_route = [&](uint32_t pre_launch, bool sample_first, hipStream_t cs) -> int {
       if constexpr (!HAS_V && (sizeof(K) == 4 || sizeof(K) == 8)) {
         uint32_t* overflow16 = reinterpret_cast<uint32_t*>(ws + L.off_err) + 2;
         uint32_t* h16 = reinterpret_cast<uint32_t*>(ws + L.off_h16);
         unsigned long long* hpos16 = reinterpret_cast<unsigned long long*>(ws + L.off_hpos16);
-        if (int r = launch_hist16<K>(keys, n, (uint32_t)blocks, km, h16, hpos16, inversion, overflow16, plan, s, sample_first, giants, pre_launch)) return r;
+        if (int r = launch_hist16<K>(keys, n, (uint32_t)blocks, km, h16, hpos16, inversion, overflow16, plan, cs, sample_first, giants, pre_launch)) return r;
         if (!pre_launch)
-            if (int r = prof_mark(*D, s, RDST_STAGE_HIST16)) return r;
+            if (int r = prof_mark(*D, cs, RDST_STAGE_HIST16)) return r;
         RouteArgs ra{};
         ra.h16 = h16;
         ra.hpos16 = hpos16;
@@ -4532,7 +4569,7 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
         ra.cursor_b = reinterpret_cast<uint32_t*>(ws + L.off_cursor_b);
         ra.xtile0 = reinterpret_cast<uint32_t*>(ws + L.off_xtile0);
         ra.skip_a_ok = sizeof(K) == 4 ? 1u : 0u;
-        hipLaunchKernelGGL(route_kernel, dim3(1), dim3(1024), 0, s, ra);
+        hipLaunchKernelGGL(route_kernel, dim3(1), dim3(1024), 0, cs, ra);
         HIP_TRY(hipGetLastError());
       }
         return RDST_OK;
@@ -4553,7 +4590,7 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
             if ((rc = launch_presample<K>(keys, n, km, plan, s))) return rc;
             if constexpr (sizeof(K) == 4 || sizeof(K) == 8) {
                 if (try_hybrid && g_tuning.exact_msd)
-                    if ((rc = count_and_route(1u, false))) return rc;
+                    if ((rc = count_and_route(1u, false, s))) return rc;
             }
             if ((rc = prof_mark(*D, s, RDST_STAGE_SAMPLE))) return rc;
             MsdRanges xr{};
@@ -4605,9 +4642,34 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
             hipLaunchKernelGGL(msd_finish_kernel, dim3(1), dim3(1024), 0, s, fa);
             HIP_TRY(hipGetLastError());
             if ((rc = prof_mark(*D, s, RDST_STAGE_ROUTE))) return rc;
+            if (g_tuning.side_stream) {
+                // The route is decided.  K4 of the atomic route follows on the caller's stream; everything the OTHER routes need —
+                // K1h, the route decision, the clears, K1, K2, the K3 passes, their K4, the giants, the copy-back: ~20 launches
+                // that return at once on the good path — goes to the library's side stream, beside K4 instead of before it
+                // (0.14 ms of 4.4 per 10^9 u32 keys, and the K3 passes need no persistent form to be cheap to skip).
+                if (!D->side_stream) {
+                    HIP_TRY(hipStreamCreateWithFlags(&D->side_stream, hipStreamNonBlocking));
+                    HIP_TRY(hipEventCreateWithFlags(&D->ev_fork, hipEventDisableTiming));
+                    HIP_TRY(hipEventCreateWithFlags(&D->ev_join, hipEventDisableTiming));
+                }
+                HIP_TRY(hipEventRecord(D->ev_fork, s));
+                rc = launch_local_sort<K>(keys, tmp, reinterpret_cast<const uint32_t*>(ws + L.off_bstart), plan, D->err_dev, km,
+                                          reinterpret_cast<uint32_t*>(ws + L.off_fblist), reinterpret_cast<uint32_t*>(ws + L.off_err) + 3,
+                                          sizeof(K) == 4 ? reinterpret_cast<const uint16_t*>(ws + L.off_halves) : nullptr, D->cus, s,
+                                          reinterpret_cast<const uint32_t*>(ws + L.off_cursor_b), L.slot_cap,
+                                          sizeof(K) == 8 ? reinterpret_cast<const K*>(ws + L.off_halves) : nullptr,
+                                          reinterpret_cast<uint32_t*>(ws + L.off_fblist2), reinterpret_cast<uint32_t*>(ws + L.off_err) + 5,
+                                          nullptr, ROUTE_ATOMIC + 1u);
+                if (rc) return rc;
+                if ((rc = prof_mark(*D, s, RDST_STAGE_LOCAL))) return rc;
+                HIP_TRY(hipStreamWaitEvent(D->side_stream, D->ev_fork, 0));
+                fs = D->side_stream;
+                forked = true;
+                if ((rc = prof_mark(*D, fs, RDST_STAGE_NONE))) return rc;
+            }
             if (!try_hybrid) {  // the LSD route's status rows, if the route fell that way
                 const uint64_t vecs = level_rows * LEVELS / 16;
-                hipLaunchKernelGGL(clear_unless_hybrid_kernel, dim3((uint32_t)D->cus * 4), dim3(256), 0, s, plan, reinterpret_cast<uint4*>(ws + L.off_status),
+                hipLaunchKernelGGL(clear_unless_hybrid_kernel, dim3((uint32_t)D->cus * 4), dim3(256), 0, fs, plan, reinterpret_cast<uint4*>(ws + L.off_status),
                                    vecs, reinterpret_cast<uint4*>(ws + L.off_status_near), vecs, 0u);
                 HIP_TRY(hipGetLastError());
             }
@@ -4615,26 +4677,26 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     }
     if constexpr (!HAS_V && (sizeof(K) == 4 || sizeof(K) == 8)) {
         if (try_hybrid) {
-            if ((rc = count_and_route(0u, !try_atomic))) return rc;
+            if ((rc = count_and_route(0u, !try_atomic, fs))) return rc;
             if (split_clear) {
                 const uint64_t vecs = level_rows * (LEVELS - 2) / 16;  // rows are multiples of 1 KiB
-                hipLaunchKernelGGL(clear_unless_hybrid_kernel, dim3((uint32_t)D->cus * 4), dim3(256), 0, s, plan,
+                hipLaunchKernelGGL(clear_unless_hybrid_kernel, dim3((uint32_t)D->cus * 4), dim3(256), 0, fs, plan,
                                    reinterpret_cast<uint4*>(ws + L.off_status), vecs, reinterpret_cast<uint4*>(ws + L.off_status_near), vecs, 0u);
                 HIP_TRY(hipGetLastError());
             } else if (try_atomic) {  // nothing was cleared up front: every level's rows, unless the atomic route took the sort
                 const uint64_t vecs = level_rows * LEVELS / 16;
-                hipLaunchKernelGGL(clear_unless_hybrid_kernel, dim3((uint32_t)D->cus * 4), dim3(256), 0, s, plan,
+                hipLaunchKernelGGL(clear_unless_hybrid_kernel, dim3((uint32_t)D->cus * 4), dim3(256), 0, fs, plan,
                                    reinterpret_cast<uint4*>(ws + L.off_status), vecs, reinterpret_cast<uint4*>(ws + L.off_status_near), vecs, 1u);
                 HIP_TRY(hipGetLastError());
             }
-            if ((rc = prof_mark(*D, s, RDST_STAGE_ROUTE))) return rc;
+            if ((rc = prof_mark(*D, fs, RDST_STAGE_ROUTE))) return rc;
         }
     }
     // a single pass (the parity hook, the sharded route's split) counts its own level only: one LDS atomic per key
-    if (LEVELS > 1 && level_hi == level_lo + 1) rc = launch_hist<K, 1>(keys, n, (uint32_t)blocks, km, hpos, hpair, false, inversion, nullptr, s, &piece, (int)level_lo);
-    else rc = launch_hist<K, LEVELS>(keys, n, (uint32_t)blocks, km, hpos, hpair, pair, inversion, (try_hybrid || try_atomic) ? plan : nullptr, s, &piece);
+    if (LEVELS > 1 && level_hi == level_lo + 1) rc = launch_hist<K, 1>(keys, n, (uint32_t)blocks, km, hpos, hpair, false, inversion, nullptr, fs, &piece, (int)level_lo);
+    else rc = launch_hist<K, LEVELS>(keys, n, (uint32_t)blocks, km, hpos, hpair, pair, inversion, (try_hybrid || try_atomic) ? plan : nullptr, fs, &piece);
     if (rc) return rc;
-    if ((rc = prof_mark(*D, s, RDST_STAGE_HIST))) return rc;
+    if ((rc = prof_mark(*D, fs, RDST_STAGE_HIST))) return rc;
     ScanArgs sa{};
     sa.hpos = hpos;
     sa.hpair = pair ? hpair : nullptr;
@@ -4655,21 +4717,22 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     sa.tile = L.tile;
     sa.use_chains = g_tuning.chains ? 1u : 0u;
     sa.halves = halves ? 1u : 0u;
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(256 * SCAN_GROUPS), 0, s, sa);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(256 * SCAN_GROUPS), 0, fs, sa);
     HIP_TRY(hipGetLastError());
-    if ((rc = prof_mark(*D, s, RDST_STAGE_SCAN))) return rc;
+    if ((rc = prof_mark(*D, fs, RDST_STAGE_SCAN))) return rc;
     for (uint32_t level = level_lo; level < level_hi; ++level) {
-        if constexpr (HAS_V) rc = launch_pass_pairs<K, V>(keys, tmp, vals, vtmp, n, (int)level, L, ws, km, D->cus, s);
-        else rc = launch_pass<K>(cfg, keys, tmp, n, (int)level, L, ws, km, D->cus, s,
+        if constexpr (HAS_V) rc = launch_pass_pairs<K, V>(keys, tmp, vals, vtmp, n, (int)level, L, ws, km, D->cus, fs);
+        else rc = launch_pass<K>(cfg, keys, tmp, n, (int)level, L, ws, km, D->cus, fs,
                                  halves && level + 1 == (uint32_t)LEVELS ? reinterpret_cast<uint16_t*>(ws + L.off_halves) : nullptr,
-                                 try_atomic && g_tuning.persist_fallback);
+                                 try_atomic && g_tuning.persist_fallback && !forked);
         if (rc) return rc;
-        if ((rc = prof_mark(*D, s, RDST_STAGE_PASS | (level << 8)))) return rc;
+        if ((rc = prof_mark(*D, fs, RDST_STAGE_PASS | (level << 8)))) return rc;
     }
     if constexpr (!HAS_V && (sizeof(K) == 4 || sizeof(K) == 8)) {
-        if (try_hybrid || try_atomic) {
+        if (try_hybrid || (try_atomic && !forked)) {
             // one K4 for both routes: the atomic route's buckets lie in the slots, the hybrid route's at their final place
-            // (4-byte keys: as low halves, in the same region of the workspace either way)
+            // (4-byte keys: as low halves, in the same region of the workspace either way).  Forked: this launch serves the
+            // hybrid route only — the atomic route's K4 ran on the caller's stream, beside all of this.
             const bool from16 = sizeof(K) == 4 && (try_atomic || halves);
             GiantArgs ga{};
             ga.glist = reinterpret_cast<uint32_t*>(ws + L.off_glist);
@@ -4679,13 +4742,13 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
             ga.recs = reinterpret_cast<GiantItem*>(ws + L.off_gsplit);
             rc = launch_local_sort<K>(keys, tmp, reinterpret_cast<const uint32_t*>(ws + L.off_bstart), plan, D->err_dev, km,
                                       reinterpret_cast<uint32_t*>(ws + L.off_fblist), reinterpret_cast<uint32_t*>(ws + L.off_err) + 3,
-                                      from16 ? reinterpret_cast<const uint16_t*>(ws + L.off_halves) : nullptr, D->cus, s,
+                                      from16 ? reinterpret_cast<const uint16_t*>(ws + L.off_halves) : nullptr, D->cus, fs,
                                       try_atomic ? reinterpret_cast<const uint32_t*>(ws + L.off_cursor_b) : nullptr, L.slot_cap,
                                       try_atomic && sizeof(K) == 8 ? reinterpret_cast<const K*>(ws + L.off_halves) : nullptr,
                                       reinterpret_cast<uint32_t*>(ws + L.off_fblist2), reinterpret_cast<uint32_t*>(ws + L.off_err) + 5,
-                                      giants ? &ga : nullptr);
+                                      giants ? &ga : nullptr, forked ? ROUTE_HYBRID + 1u : 0u);
             if (rc) return rc;
-            if ((rc = prof_mark(*D, s, RDST_STAGE_LOCAL))) return rc;
+            if ((rc = prof_mark(*D, fs, RDST_STAGE_LOCAL))) return rc;
         }
     }
     if (copy_back) {
@@ -4697,9 +4760,9 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
         const Plan* plan = reinterpret_cast<const Plan*>(ws + L.off_plan);
         constexpr int VEC = 16 / sizeof(K);
         if (aligned)
-            hipLaunchKernelGGL((copyback_kernel<K, VEC>), dim3((uint32_t)cblocks), dim3(256), 0, s, keys, tmp, n, plan);
+            hipLaunchKernelGGL((copyback_kernel<K, VEC>), dim3((uint32_t)cblocks), dim3(256), 0, fs, keys, tmp, n, plan);
         else
-            hipLaunchKernelGGL((copyback_kernel<K, 1>), dim3((uint32_t)cblocks), dim3(256), 0, s, keys, tmp, n, plan);
+            hipLaunchKernelGGL((copyback_kernel<K, 1>), dim3((uint32_t)cblocks), dim3(256), 0, fs, keys, tmp, n, plan);
         HIP_TRY(hipGetLastError());
         if constexpr (HAS_V) {
             const bool valigned = ((reinterpret_cast<uintptr_t>(vals) | reinterpret_cast<uintptr_t>(vtmp)) & 15u) == 0;
@@ -4708,12 +4771,16 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
             if (vblocks < 1) vblocks = 1;
             constexpr int VVEC = 16 / sizeof(V);
             if (valigned)
-                hipLaunchKernelGGL((copyback_kernel<V, VVEC>), dim3((uint32_t)vblocks), dim3(256), 0, s, vals, vtmp, n, plan);
+                hipLaunchKernelGGL((copyback_kernel<V, VVEC>), dim3((uint32_t)vblocks), dim3(256), 0, fs, vals, vtmp, n, plan);
             else
-                hipLaunchKernelGGL((copyback_kernel<V, 1>), dim3((uint32_t)vblocks), dim3(256), 0, s, vals, vtmp, n, plan);
+                hipLaunchKernelGGL((copyback_kernel<V, 1>), dim3((uint32_t)vblocks), dim3(256), 0, fs, vals, vtmp, n, plan);
             HIP_TRY(hipGetLastError());
         }
-        if ((rc = prof_mark(*D, s, RDST_STAGE_COPYBACK))) return rc;
+        if ((rc = prof_mark(*D, fs, RDST_STAGE_COPYBACK))) return rc;
+    }
+    if (forked) {  // join: the caller's stream continues when the side stream is through
+        HIP_TRY(hipEventRecord(D->ev_join, fs));
+        HIP_TRY(hipStreamWaitEvent(s, D->ev_join, 0));
     }
     if (layout_out) *layout_out = L;
     if (ws_out) *ws_out = ws;
@@ -4952,6 +5019,10 @@ int rdst_hip_set_hybrid(int enabled, uint64_t min_len) {
     g_tuning.atomic_route = g_tuning.atomic_route || enabled == 10;
     g_tuning.expand = enabled != 9;        // 9: the K1h hybrid route without the expanding K4 (buckets up to one tile; refused buckets to the ranked kernel) (A/B, tests)
     g_tuning.atomic_wide = enabled != 8;   // 8: the atomic route for 4-byte keys only, 8-byte keys on the K1h hybrid route (A/B, tests)
+    g_tuning.side_stream = enabled != 13;  // 13: the default with every launch on the caller's stream (the fallback's K3 passes in their persistent form) (A/B, tests)
+    g_tuning.atomic_route = g_tuning.atomic_route || enabled == 13;
+    g_tuning.predict = enabled != 14;      // 14: the default without the sample's prediction of the LSD route (A/B, tests)
+    g_tuning.atomic_route = g_tuning.atomic_route || enabled == 14;
     g_tuning.hybrid_min_len = min_len ? min_len : (1ull << 28);
     return RDST_OK;
 }
@@ -5111,10 +5182,12 @@ int rdst_hip_profile_run(int run, float* out_ms, uint32_t capacity, uint32_t* n_
     if (run < 0 || run >= (int)D->prof_runs.size()) return fail(RDST_ERR_ARG, "no such profiled run");
     const auto r = D->prof_runs[run];
     if (r.count < 2) return RDST_OK;
-    HIP_TRY(hipEventSynchronize(D->prof_events[r.begin + r.count - 1]));
+    for (uint32_t i = 0; i < r.count; ++i) HIP_TRY(hipEventSynchronize(D->prof_events[r.begin + i]));  // (two streams: the last event need not be the last to complete)
     const uint32_t n = r.count - 1;
-    for (uint32_t i = 0; i < n && i < capacity; ++i)
+    for (uint32_t i = 0; i < n && i < capacity; ++i) {
+        if ((D->prof_kinds[r.begin + i] & 0xFFu) == RDST_STAGE_NONE) { out_ms[i] = 0.0f; continue; }  // the two events lie on different streams
         HIP_TRY(hipEventElapsedTime(&out_ms[i], D->prof_events[r.begin + i], D->prof_events[r.begin + i + 1]));
+    }
     *n_out = n < capacity ? n : capacity;
     return RDST_OK;
 }

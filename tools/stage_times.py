@@ -19,16 +19,22 @@ tmp = torch.empty_like(src).view(getattr(torch, name))
 for mode in modes:
     rdst_amd.set_hybrid(mode if mode else False)
     acc = {}
-    for rep in range(4):
+    wall = []
+    for rep in range(6):
         buf = src.clone().view(getattr(torch, name))
         rdst_amd.set_profiling(True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         rdst_amd.sort_device_tensor(buf, tmp)
+        e1.record()
+        torch.cuda.synchronize()
         p = rdst_amd.profile_run(-1, buf.element_size())
         rdst_amd.set_profiling(False)
         if rep == 0:
             continue
+        wall.append(e0.elapsed_time(e1))
         for i, (nm, lv, ms) in enumerate(p["stages"]):
             acc.setdefault((i, nm, lv), []).append(ms)
     total = sum(sum(v) / len(v) for v in acc.values())
-    print(f"mode {mode} route {rdst_amd.last_route()} total {total:.3f} ms  " +
+    print(f"mode {mode} route {rdst_amd.last_route()} wall {sum(wall) / len(wall):.3f} ms (stages sum {total:.3f})  " +
           "  ".join(f"{nm}{'' if lv is None else lv}={sum(v) / len(v):.3f}" for (i, nm, lv), v in sorted(acc.items())))
