@@ -1868,30 +1868,36 @@ __global__ __launch_bounds__(NWAVES * 64, RDST_MSD_MINWAVES) void msd_scatter_ke
         // the sample already gave the route up (plan words and pass A's inversion flag are written by EARLIER launches: block-uniform)
         if (plan->gross_skew || plan->top_skew || plan->predict_lsd) return;
         if (SECOND && *inversion == 0) return;  // pass A met no inversion: the slice is sorted, nothing to do
-        // ... or an earlier tile did (a coherent load: the flag is raised by blocks on other XCDs WHILE this kernel runs, so two
-        // waves of one block can see different values — the exit must be the block's, not the wave's: a wave that left alone
-        // would leave its stale wave_hist table to be summed into the claims of the waves that stayed)
-#ifndef RDST_MSD_EXIT
-#define RDST_MSD_EXIT 0  // 0: decided at the top of the kernel; 2: the flag is requested at the top and looked at behind the tile's loads, at the first barrier the kernel has anyway
-#endif
-#ifdef RDST_MSD_WAVE_EXIT  // (tools build, A/B only: round 2's per-wave exit, unsafe with the knob set_hybrid(..., min_len) lowered)
-        if (ld_relaxed<uint32_t>(overflow)) return;
-#elif RDST_MSD_EXIT == 0
-        if (__syncthreads_or((int)ld_relaxed<uint32_t>(overflow))) return;
-#endif
     }
-    uint32_t gave_up = 0;
-#if RDST_MSD_EXIT == 2 && !defined(RDST_MSD_WAVE_EXIT)
-    if (!exact) gave_up = ld_relaxed<uint32_t>(overflow);
-#endif
     const int win = exact ? 0 : (int)plan->win_shift;  // the buckets' 16 bits start this far below the key's top (presample_kernel)
     shift -= win;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* wave_hist = reinterpret_cast<uint32_t*>(smem);                           // [NWAVES][256]
     uint32_t* s_delta = reinterpret_cast<uint32_t*>(smem + NWAVES * 1024);             // [256] destination of tile slot 0 of a digit's run (elements, mod 2^32)
-    uint32_t* s_misc = reinterpret_cast<uint32_t*>(smem + NWAVES * 1024 + 1024);       // [32]
+    uint32_t* s_misc = reinterpret_cast<uint32_t*>(smem + NWAVES * 1024 + 1024);       // [32]; [16 + w]: what wave w saw in the overflow flag
     K* s_keys = reinterpret_cast<K*>(smem + NWAVES * 1024 + 1024 + 128);               // [TILE]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // ... or an earlier tile did.  The flag is raised by blocks on other XCDs WHILE this kernel runs (hence a coherent load), so two
+    // waves of one block can see different values — and the exit must be the BLOCK's: a wave that left alone would leave its
+    // stale wave_hist table to be summed into the claims of the waves that stayed (round 2 did that; with the knob
+    // set_hybrid(..., min_len) lowered the garbage claims could store outside the workspace).  Block-uniform without a barrier of
+    // its own (__syncthreads_or is a software reduction, two barriers and LDS traffic: +0.1 ms per pass when it sat here):
+    // every wave leaves what it saw in its own word of s_misc before the barrier the kernel has anyway, behind the tile's loads
+    // and counts, and every thread reads all the words behind it.  Pass B does not even wait for the flag before its loads (the
+    // latency hides behind them: -2 %); a wave of pass A does, and one that finds the flag up goes straight to that barrier
+    // without loading anything — behind a failed claim the rest of the pass costs microseconds, not a read of the slice.
+    static_assert(NWAVES <= 16, "one word of s_misc per wave");
+    uint32_t gave_up = 0;
+    if (!exact) {
+        gave_up = ld_relaxed<uint32_t>(overflow);
+        if constexpr (!SECOND) {
+            if (gave_up) {
+                if (lane == 0) s_misc[16 + wave] = 1u;
+                __syncthreads();
+                return;
+            }
+        }
+    }
     uint32_t area = blockIdx.x / tiles_per_area, j = blockIdx.x % tiles_per_area;
     if constexpr (SECOND) {
         // pass B of the atomic route: a slot (top digit d, second digit) is appended to by the tiles of d's eight areas.  Blocks b
@@ -2064,22 +2070,14 @@ __global__ __launch_bounds__(NWAVES * 64, RDST_MSD_MINWAVES) void msd_scatter_ke
         }
     }
     RDST_STAMP(2);
-#if RDST_MSD_EXIT == 2 && !defined(RDST_MSD_WAVE_EXIT)
-    // block-uniform without a barrier of its own (__syncthreads_or is a software reduction: two barriers and LDS traffic): every
-    // wave leaves what it saw in its own word before the barrier the kernel has anyway, every thread reads all the words behind it
-    static_assert(NWAVES <= 16, "one word of s_misc per wave");
     if (lane == 0) s_misc[16 + wave] = gave_up;
     __syncthreads();
     {
         uint32_t any = 0;
 #pragma unroll
         for (int w = 0; w < NWAVES; ++w) any |= s_misc[16 + w];
-        if (any) return;  // the flag's latency hid behind the tile's loads
+        if (any) return;  // block-uniform (see the top of the kernel)
     }
-#else
-    (void)gave_up;
-    __syncthreads();
-#endif
     RDST_STAMP(3);
     if (tid < RADIX) __builtin_amdgcn_s_setprio(RDST_PRIO_SCAN);
     uint32_t cw[NWAVES];
@@ -2527,9 +2525,8 @@ template <typename K, int NWAVES, int KPT, bool MAPPED>
 __global__ __launch_bounds__(NWAVES * 64, (sizeof(K) <= 4 ? 2 : 1) * NWAVES / 4) void local_sort_kernel(
     K* __restrict__ buf_keys, K* __restrict__ buf_tmp, const uint32_t* __restrict__ bstart, const Plan* __restrict__ plan,
     uint32_t* __restrict__ err, K neg, K pos, uint32_t flags, const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count,
-    const uint16_t* __restrict__ src16, const uint32_t* __restrict__ slot_count, uint32_t slot_cap, const K* __restrict__ alt_src,
-    uint32_t only_route /* 0, or ROUTE_x + 1: this launch serves that route only (the fallback routes' launches run on a side stream) */) {
-    if (!plan->local_sort || (only_route && plan->route + 1u != only_route)) return;
+    const uint16_t* __restrict__ src16, const uint32_t* __restrict__ slot_count, uint32_t slot_cap, const K* __restrict__ alt_src) {
+    if (!plan->local_sort) return;
     if (plan->route != ROUTE_ATOMIC) { slot_count = nullptr; alt_src = nullptr; }  // the hybrid route's buckets lie at their final place
     K* __restrict__ buf = plan->result_in_tmp ? buf_tmp : buf_keys;
     if (list == nullptr) {
@@ -2578,13 +2575,12 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 8 : 6) void local_count_sort
     uint32_t* __restrict__ buf_keys, uint32_t* __restrict__ buf_tmp, const uint16_t* __restrict__ src16, const uint32_t* __restrict__ bstart,
     const Plan* __restrict__ plan, uint32_t* __restrict__ err, uint32_t neg, uint32_t pos, uint32_t* __restrict__ list,
     uint32_t* __restrict__ list_count, const uint32_t* __restrict__ slot_count /* ROUTE_ATOMIC: bucket b's halves lie in slot b (slot_cap
-    entries) of src16 and number slot_count[b]; NULL: they lie at their final place, bstart */, uint32_t slot_cap,
-    uint32_t only_route /* 0, or ROUTE_x + 1: this launch serves that route only (the fallback routes' launches run on a side stream) */) {
+    entries) of src16 and number slot_count[b]; NULL: they lie at their final place, bstart */, uint32_t slot_cap) {
     constexpr int MAXR = (COUNT_TILE + BLOCK - 1) / BLOCK;
     constexpr int VPT = H16_BINS / BLOCK, WPT = VPT / 8;  // values / counter words per thread
     constexpr int LOG_VPT = BLOCK == 1024 ? 6 : (BLOCK == 512 ? 7 : 8);
     static_assert((1 << LOG_VPT) == VPT, "block size");
-    if (!plan->local_sort || (only_route && plan->route + 1u != only_route)) return;
+    if (!plan->local_sort) return;
     if (plan->route != ROUTE_ATOMIC) slot_count = nullptr;  // the hybrid route's buckets lie at their final place (src16: position for position)
     uint32_t* __restrict__ buf = plan->result_in_tmp ? buf_tmp : buf_keys;
     const uint32_t bucket = blockIdx.x;
@@ -2742,10 +2738,9 @@ template <bool MAPPED, bool FROM16>
 __global__ __launch_bounds__(EXPAND_THREADS) void local_expand_sort_kernel(
     uint32_t* __restrict__ buf_keys, uint32_t* __restrict__ buf_tmp, const uint16_t* __restrict__ src16, const uint32_t* __restrict__ bstart,
     const Plan* __restrict__ plan, uint32_t* __restrict__ err, uint32_t neg, uint32_t pos, const uint32_t* __restrict__ list,
-    const uint32_t* __restrict__ list_count, const uint32_t* __restrict__ slot_count, uint32_t slot_cap,
-    uint32_t only_route /* 0, or ROUTE_x + 1: this launch serves that route only (the fallback routes' launches run on a side stream) */) {
+    const uint32_t* __restrict__ list_count, const uint32_t* __restrict__ slot_count, uint32_t slot_cap) {
     constexpr int BLOCK = EXPAND_THREADS, WPT = H16_BINS / 2 / BLOCK;  // 32 words of two counters per thread
-    if (!plan->local_sort || (only_route && plan->route + 1u != only_route)) return;
+    if (!plan->local_sort) return;
     if (plan->route != ROUTE_ATOMIC) slot_count = nullptr;
     uint32_t* __restrict__ buf = plan->result_in_tmp ? buf_tmp : buf_keys;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -2859,10 +2854,9 @@ template <bool MAPPED, bool FROM16>
 __global__ __launch_bounds__(COUNT16_THREADS) void local_count16_sort_kernel(
     uint32_t* __restrict__ buf_keys, uint32_t* __restrict__ buf_tmp, const uint16_t* __restrict__ src16, const uint32_t* __restrict__ bstart,
     const Plan* __restrict__ plan, uint32_t neg, uint32_t pos, const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count,
-    uint32_t* __restrict__ list2, uint32_t* __restrict__ list2_count, const uint32_t* __restrict__ slot_count, uint32_t slot_cap,
-    uint32_t only_route /* 0, or ROUTE_x + 1: this launch serves that route only (the fallback routes' launches run on a side stream) */) {
+    uint32_t* __restrict__ list2, uint32_t* __restrict__ list2_count, const uint32_t* __restrict__ slot_count, uint32_t slot_cap) {
     constexpr int BLOCK = COUNT16_THREADS, KPT = COUNT16_KPT, WPT = H16_BINS / 2 / BLOCK;
-    if (!plan->local_sort || (only_route && plan->route + 1u != only_route)) return;
+    if (!plan->local_sort) return;
     if (plan->route != ROUTE_ATOMIC) slot_count = nullptr;
     uint32_t* __restrict__ buf = plan->result_in_tmp ? buf_tmp : buf_keys;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -3277,11 +3271,10 @@ static_assert(WIDE_TILE % (2 * WIDE_THREADS) == 0, "two output halves of whole r
 template <bool MAPPED>
 __global__ __launch_bounds__(WIDE_THREADS, 4) void local_wide_sort_kernel(
     uint64_t* __restrict__ buf_keys, uint64_t* __restrict__ buf_tmp, const uint32_t* __restrict__ bstart, const Plan* __restrict__ plan,
-    uint32_t* __restrict__ err, uint64_t neg, uint64_t pos, uint32_t* __restrict__ list, uint32_t* __restrict__ list_count,
-    uint32_t only_route /* 0, or ROUTE_x + 1: this launch serves that route only (the fallback routes' launches run on a side stream) */) {
+    uint32_t* __restrict__ err, uint64_t neg, uint64_t pos, uint32_t* __restrict__ list, uint32_t* __restrict__ list_count) {
     constexpr int BLOCK = WIDE_THREADS, MAXR = WIDE_TILE / BLOCK, WPT = H16_BINS / BLOCK / 8, LOG_VPT = 6;
     constexpr int HALF = WIDE_TILE / 2;
-    if (!plan->local_sort || (only_route && plan->route + 1u != only_route)) return;
+    if (!plan->local_sort) return;
     uint64_t* __restrict__ buf = plan->result_in_tmp ? buf_tmp : buf_keys;
     const uint32_t bucket = blockIdx.x;
     const uint32_t start = bstart[bucket], cnt = bstart[bucket + 1] - start;
@@ -3431,13 +3424,12 @@ __global__ __launch_bounds__(WIDE2_THREADS, 8) void local_wide2_sort_kernel(
     uint64_t* __restrict__ buf_keys, uint64_t* __restrict__ buf_tmp, const uint32_t* __restrict__ bstart, const Plan* __restrict__ plan,
     uint32_t* __restrict__ err, uint64_t neg, uint64_t pos, uint32_t* __restrict__ list, uint32_t* __restrict__ list_count,
     const uint64_t* __restrict__ src_slots /* ROUTE_ATOMIC: bucket b's keys lie in slot b (slot_cap keys) and number slot_count[b]; NULL: in place */,
-    const uint32_t* __restrict__ slot_count, uint32_t slot_cap,
-    uint32_t only_route /* 0, or ROUTE_x + 1: this launch serves that route only (the fallback routes' launches run on a side stream) */) {
+    const uint32_t* __restrict__ slot_count, uint32_t slot_cap) {
     constexpr int TILE = local_tile(8);
     constexpr int BLOCK = WIDE2_THREADS, MAXR = TILE / BLOCK, WPT = H16_BINS / BLOCK / 8, LOG_VPT = 6;
     constexpr int HALF = TILE / 2;
     static_assert((size_t)HALF * 8 <= 32768 + 8192 + 2 * (size_t)TILE, "output staging fits the dead tables");
-    if (!plan->local_sort || (only_route && plan->route + 1u != only_route)) return;
+    if (!plan->local_sort) return;
     if (plan->route != ROUTE_ATOMIC) src_slots = nullptr;  // the hybrid route's buckets lie at their final place
     uint64_t* __restrict__ buf = plan->result_in_tmp ? buf_tmp : buf_keys;
     const uint32_t bucket = blockIdx.x;
@@ -3577,6 +3569,184 @@ __global__ __launch_bounds__(WIDE2_THREADS, 8) void local_wide2_sort_kernel(
             const uint32_t idx = (uint32_t)tid + i * BLOCK;
             const uint32_t rel = (uint32_t)(mk[i] >> 48) - (uint32_t)(h * HALF);
             if (idx < cnt && rel < (uint32_t)HALF) out64[rel] = (mk[i] & LOW48) | ((uint64_t)bucket_prefix16(plan, bucket) << 48);
+        }
+        __syncthreads();
+        if (h == 0) RDST_STAMP(7);
+        __builtin_amdgcn_s_setprio(RDST_PRIO_SCATTER);
+#pragma unroll
+        for (int i = 0; i < HALF / BLOCK; ++i) {
+            const uint32_t rel = (uint32_t)tid + i * BLOCK, at = rel + (uint32_t)(h * HALF);
+            if (at < cnt) tdst[at] = MAPPED ? unmap_key<uint64_t>(out64[rel], neg, pos) : out64[rel];
+        }
+        if (h == 0) __syncthreads();  // the second half reuses the staging
+        if (h == 0) RDST_STAMP(8);
+    }
+    RDST_STAMP(9);
+    RDST_TL_END(bucket);
+}
+
+// K4 for 8-byte keys, third form: local_wide2_sort_kernel with a third fewer LDS instructions.  By the kernel's timeline
+// (tools/timeline2.py, round 3) a bucket's 31.8 us were 25 us of LDS-bound phases — ties 8.8, staging 6, scan 3.8, place 3.0,
+// count 2.9 — against 4 us of loads and 3 of stores: two blocks per CU kept the ONE LDS busy, not the HBM.  Changes:
+//  * a prefix per counter word again (16 KiB instead of 8: the block takes exactly half of the CU's 160 KiB, the wave sums and
+//    the flag live in corners of the staged-bits array that are free when they are needed) — a key in an odd word no longer
+//    reads the even word as well, in the place phase and in the tie phase;
+//  * a key's index among equals and the size of its group are kept in two packed register pairs (4 bits x 16 keys each)
+//    instead of being re-read: the tie phase reads nothing but the staged bits of the group's members, and only for keys
+//    that have company (one in five on uniform keys).
+constexpr int WIDE3_THREADS = 1024;
+constexpr size_t wide3_lds_bytes() { return 32768 + 16384 + 2 * (size_t)local_tile(8); }  // 81 920 = 160 KiB / 2
+static_assert(wide3_lds_bytes() * 2 <= 160 * 1024, "two blocks per CU");
+
+template <bool MAPPED>
+__global__ __launch_bounds__(WIDE3_THREADS, 8) void local_wide3_sort_kernel(
+    uint64_t* __restrict__ buf_keys, uint64_t* __restrict__ buf_tmp, const uint32_t* __restrict__ bstart, const Plan* __restrict__ plan,
+    uint32_t* __restrict__ err, uint64_t neg, uint64_t pos, uint32_t* __restrict__ list, uint32_t* __restrict__ list_count,
+    const uint64_t* __restrict__ src_slots /* ROUTE_ATOMIC: bucket b's keys lie in slot b (slot_cap keys) and number slot_count[b]; NULL: in place */,
+    const uint32_t* __restrict__ slot_count, uint32_t slot_cap) {
+    constexpr int TILE = local_tile(8);
+    constexpr int BLOCK = WIDE3_THREADS, MAXR = TILE / BLOCK, WPT = H16_BINS / BLOCK / 8, LOG_VPT = 6;
+    constexpr int HALF = TILE / 2;
+    static_assert(MAXR == 16, "two 64-bit registers of 4-bit fields, one field per key");
+    static_assert((size_t)HALF * 8 <= 32768 + 16384 + 2 * (size_t)TILE - 4, "output staging fits below the flag word");
+    if (!plan->local_sort) return;
+    if (plan->route != ROUTE_ATOMIC) src_slots = nullptr;  // the hybrid route's buckets lie at their final place
+    uint64_t* __restrict__ buf = plan->result_in_tmp ? buf_tmp : buf_keys;
+    const uint32_t bucket = blockIdx.x;
+    const uint32_t start = bstart[bucket], cnt = src_slots ? slot_count[bucket] : bstart[bucket + 1] - start;
+    if (cnt == 0 || (cnt == 1 && !src_slots)) return;  // (a single key in a slot still has to be moved to its place)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (cnt > (uint32_t)TILE) {
+        if (tid == 0) atomicOr(err, ERR_LOCAL_OVERFLOW);
+        return;
+    }
+    if (cnt > (uint32_t)TILE - 2u) {  // the last two entries of the staged bits are the flag word: such a bucket goes to the generic kernel
+        if (tid == 0) list[atomicAdd(list_count, 1u)] = bucket;
+        return;
+    }
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* cnt4 = reinterpret_cast<uint32_t*>(smem);                              // [WPT][BLOCK] eight 4-bit counters per word
+    uint16_t* prefix = reinterpret_cast<uint16_t*>(smem + 32768);                    // [WPT][BLOCK] keys below the word
+    uint16_t* mid16 = reinterpret_cast<uint16_t*>(smem + 32768 + 16384);             // [TILE] bits [16, 32) of the keys at their slots
+    uint32_t* s_wsum = reinterpret_cast<uint32_t*>(smem + 32768 + 16384);            // [16] wave sums (scan phase: the staged bits are not there yet)
+    uint32_t* s_flag = reinterpret_cast<uint32_t*>(smem + 32768 + 16384 + 2 * TILE - 4);  // overflow / ambiguity (never a slot: cnt <= TILE - 2)
+    uint64_t* out64 = reinterpret_cast<uint64_t*>(smem);                             // [HALF] output staging (the tables are dead by then)
+    RDST_TL_BEGIN(1);
+    __builtin_amdgcn_s_setprio(RDST_PRIO_LOAD);
+    const uint64_t* tsrc = src_slots ? src_slots + (uint64_t)bucket * slot_cap : buf + start;
+    uint64_t mk[MAXR];
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) {
+        const uint32_t idx = (uint32_t)tid + i * BLOCK;
+        mk[i] = tsrc[idx < cnt ? idx : cnt - 1];
+    }
+#pragma unroll
+    for (int k = 0; k < WPT; ++k) cnt4[k * BLOCK + tid] = 0;
+    if (tid == 0) *s_flag = 0;
+    RDST_STAMP(1);
+    __syncthreads();
+    RDST_STAMP(2);
+    __builtin_amdgcn_s_setprio(0);
+    auto word_of = [](uint32_t v) -> uint32_t { return ((v >> 3) & (uint32_t)(WPT - 1)) * BLOCK + (v >> LOG_VPT); };
+    constexpr uint64_t LOW48 = (1ull << 48) - 1;  // a key's slot rides in its top 16 bits (the bucket index, restored at the end)
+    uint64_t mine_pack = 0, group_pack = 0;       // per key: index among the keys of its value, size of that group
+    bool flag = false;
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) {
+        const uint32_t idx = (uint32_t)tid + i * BLOCK;
+        if (idx < cnt) {
+            if constexpr (MAPPED) mk[i] = map_key<uint64_t>(mk[i], neg, pos);
+            const uint32_t v = (uint32_t)(mk[i] >> 32) & 0xFFFFu;
+            const uint32_t sh = (v & 7u) * 4u;
+            const uint32_t old = atomicAdd(&cnt4[word_of(v)], 1u << sh);
+            const uint32_t mine = (old >> sh) & 15u;
+            flag |= mine == 15u;
+            mine_pack |= (uint64_t)mine << (4 * i);
+        }
+    }
+    if (flag) *s_flag = 1;
+    RDST_STAMP(3);
+    __syncthreads();
+    if (*s_flag) {  // block-uniform: the bucket stays as it is, for the generic kernel
+        if (tid == 0) list[atomicAdd(list_count, 1u)] = bucket;
+        return;
+    }
+    {
+        uint32_t pre[WPT];
+        uint32_t run = 0;
+#pragma unroll
+        for (int k = 0; k < WPT; ++k) {
+            pre[k] = run;
+            run = nibble_sum(cnt4[k * BLOCK + tid], run);
+        }
+        uint32_t incl = run;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(incl, o);
+            if (lane >= o) incl += y;
+        }
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        uint32_t base = incl - run;
+#pragma unroll
+        for (int x = 0; x < BLOCK / 64; ++x)
+            if (x < wave) base += s_wsum[x];
+#pragma unroll
+        for (int k = 0; k < WPT; ++k) prefix[k * BLOCK + tid] = (uint16_t)(base + pre[k]);
+    }
+    __syncthreads();  // (also: every read of the wave sums is done before the staged bits overwrite them)
+    RDST_STAMP(4);
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) {
+        const uint32_t idx = (uint32_t)tid + i * BLOCK;
+        if (idx < cnt) {
+            const uint32_t v = (uint32_t)(mk[i] >> 32) & 0xFFFFu;
+            const uint32_t wd = word_of(v), sh = (v & 7u) * 4u;
+            const uint32_t w = cnt4[wd];
+            const uint32_t first = nibble_sum(w & ((1u << sh) - 1u), (uint32_t)prefix[wd]);
+            const uint32_t slot = first + ((uint32_t)(mine_pack >> (4 * i)) & 15u);
+            group_pack |= (uint64_t)((w >> sh) & 15u) << (4 * i);
+            mid16[slot] = (uint16_t)((uint32_t)mk[i] >> 16);
+            mk[i] = (mk[i] & LOW48) | ((uint64_t)slot << 48);
+        }
+    }
+    RDST_STAMP(5);
+    __syncthreads();
+    // ties: my place inside my group = members with smaller bits [16, 32) (equal ones would need the low 16 bits: give up)
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) {
+        const uint32_t group = (uint32_t)(group_pack >> (4 * i)) & 15u;  // (0 for the slots past cnt)
+        if (group >= 2u) {
+            const uint32_t slot = (uint32_t)(mk[i] >> 48);
+            const uint32_t first = slot - ((uint32_t)(mine_pack >> (4 * i)) & 15u);
+            const uint32_t mid = ((uint32_t)mk[i] >> 16) & 0xFFFFu;
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < group; ++j) {
+                const uint32_t other = mid16[first + j];
+                rank += other < mid ? 1u : 0u;
+                flag |= other == mid && first + j != slot;
+            }
+            mk[i] = (mk[i] & LOW48) | ((uint64_t)(first + rank) << 48);
+        }
+    }
+    if (flag) *s_flag = 1;
+    RDST_STAMP(6);
+    __syncthreads();  // every look at the tables and the staged bits is done: their space becomes the output staging
+    if (*s_flag) {
+        if (tid == 0) list[atomicAdd(list_count, 1u)] = bucket;
+        return;
+    }
+    uint64_t* tdst = buf + start;
+    const uint64_t top = (uint64_t)bucket_prefix16(plan, bucket) << 48;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (h == 1 && cnt <= (uint32_t)HALF) break;  // block-uniform
+        __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i) {
+            const uint32_t idx = (uint32_t)tid + i * BLOCK;
+            const uint32_t rel = (uint32_t)(mk[i] >> 48) - (uint32_t)(h * HALF);
+            if (idx < cnt && rel < (uint32_t)HALF) out64[rel] = (mk[i] & LOW48) | top;
         }
         __syncthreads();
         if (h == 0) RDST_STAMP(7);
@@ -3825,6 +3995,7 @@ struct Tuning {
     bool halves = true;                 // 4-byte keys: pass L-1 hands K4 the low halves only (16-bit array in the workspace)
     bool presample = true;              // a 65 536-key sample before K1h: gross skew goes straight to the LSD route
     bool wide2 = true;                  // 8-byte keys: K4 as two 512-thread blocks per CU (false: one 1024-thread block)
+    bool wide3 = true;                  // ... in its third form (local_wide3_sort_kernel); false: local_wide2_sort_kernel
     bool atomic_route = true;           // 4-byte keys: try ROUTE_ATOMIC (no counting read) before anything else
     bool exact_msd = true;              // behind a sample that flags the keys, K1h runs before the MSD passes and they take their exact form for the hybrid route
     bool giants = true;                 // 4-byte keys, hybrid route: buckets of 65 536 keys and more are sorted by the giant kernels (else: LSD route)
@@ -3833,7 +4004,6 @@ struct Tuning {
     bool atomic_wide = true;            // ROUTE_ATOMIC for 8-byte keys too (whole keys in the slots)
     bool persist_fallback = true;       // behind the atomic route the LSD passes run as persistent blocks (cheap to skip)
     bool predict = true;                // the sample may predict the LSD route (Plan::predict_lsd): neither MSD passes nor K1h are tried
-    bool side_stream = true;            // behind a tried atomic route the fallback routes' launches go to a side stream (DeviceState::side_stream)
     uint64_t hybrid_min_len = 1ull << 28;  // below this the buckets are too small for one workgroup each to pay off
 };
 uint32_t g_ablate = 0;  // only ever set by the RDST_EXPERIMENTS build
@@ -3859,10 +4029,6 @@ struct DeviceState {
     std::mutex host_mutex;              // one host-slice sort per device at a time (they share stream and buffer)
     hipEvent_t host_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // around H2D, sort, D2H of the most recent host-slice sort
     bool host_timed = false;
-    // The fallback routes' launches behind a tried atomic route run on a stream of the library's own, forked after the route
-    // decision and joined at the end: on the good path their ~20 launches return at once BESIDE K4 instead of before it
-    hipStream_t side_stream = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t last_done = nullptr;  // recorded after every enqueue that uses the workspace
     hipStream_t last_stream = nullptr;
     bool have_last = false;
@@ -4050,9 +4216,7 @@ int workspace_release(DeviceState& D, hipStream_t s) {
     return RDST_OK;
 }
 
-// `kind`: the stage that ENDS at this mark (ignored for a run's first mark).  RDST_STAGE_NONE: no stage — this mark is the first one
-// on another stream, the interval before it means nothing (rdst_hip_profile_run reports 0 for it)
-constexpr uint32_t RDST_STAGE_NONE = 0xFF;
+// `kind`: the stage that ENDS at this mark (ignored for a run's first mark)
 int prof_mark(DeviceState& D, hipStream_t s, uint32_t kind = 0) {
     if (!g_tuning.profiling || D.prof_runs.empty() || D.prof_used >= 8192) return RDST_OK;
     if (D.prof_used == D.prof_events.size()) {
@@ -4207,7 +4371,7 @@ template <typename K>
 int launch_local_sort(K* keys, K* tmp, const uint32_t* bstart, const Plan* plan, uint32_t* err, KeyMap km, uint32_t* list,
                       uint32_t* list_count, const uint16_t* src16, int cus, hipStream_t s, const uint32_t* slot_count = nullptr,
                       uint32_t slot_cap = 0, const K* src_slots = nullptr, uint32_t* list2 = nullptr, uint32_t* list2_count = nullptr,
-                      const GiantArgs* ga = nullptr, uint32_t only_route = 0) {
+                      const GiantArgs* ga = nullptr) {
     constexpr int NW = local_waves(sizeof(K)), KPT = local_kpt(sizeof(K));
     constexpr size_t lds = local_lds_bytes(sizeof(K));
     const bool mapped = km.neg != 0 || km.pos != 0;
@@ -4220,7 +4384,7 @@ int launch_local_sort(K* keys, K* tmp, const uint32_t* bstart, const Plan* plan,
     do {                                                                                                                             \
         if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_count_sort_kernel<COUNT_THREADS, MAPPED, FROM16>), clds)) return rc; \
         hipLaunchKernelGGL((local_count_sort_kernel<COUNT_THREADS, MAPPED, FROM16>), dim3(H16_BINS), dim3(COUNT_THREADS), clds, s, keys, tmp, \
-                           src16, bstart, plan, err, (uint32_t)km.neg, (uint32_t)km.pos, list, list_count, slot_count, slot_cap, only_route); \
+                           src16, bstart, plan, err, (uint32_t)km.neg, (uint32_t)km.pos, list, list_count, slot_count, slot_cap); \
     } while (0)
             if (src16) { if (mapped) RDST_COUNT(true, true); else RDST_COUNT(false, true); }
             else { if (mapped) RDST_COUNT(true, false); else RDST_COUNT(false, false); }
@@ -4232,7 +4396,7 @@ int launch_local_sort(K* keys, K* tmp, const uint32_t* bstart, const Plan* plan,
     do {                                                                                                                             \
         if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_count16_sort_kernel<MAPPED, FROM16>), elds)) return rc;    \
         hipLaunchKernelGGL((local_count16_sort_kernel<MAPPED, FROM16>), dim3((uint32_t)cus), dim3(COUNT16_THREADS), elds, s, keys, tmp, \
-                           src16, bstart, plan, (uint32_t)km.neg, (uint32_t)km.pos, list, list_count, list2, list2_count, slot_count, slot_cap, only_route); \
+                           src16, bstart, plan, (uint32_t)km.neg, (uint32_t)km.pos, list, list_count, list2, list2_count, slot_count, slot_cap); \
     } while (0)
                 if (src16) { if (mapped) RDST_COUNT16(true, true); else RDST_COUNT16(false, true); }
                 else { if (mapped) RDST_COUNT16(true, false); else RDST_COUNT16(false, false); }
@@ -4242,7 +4406,7 @@ int launch_local_sort(K* keys, K* tmp, const uint32_t* bstart, const Plan* plan,
     do {                                                                                                                             \
         if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_expand_sort_kernel<MAPPED, FROM16>), elds)) return rc;     \
         hipLaunchKernelGGL((local_expand_sort_kernel<MAPPED, FROM16>), dim3((uint32_t)cus), dim3(EXPAND_THREADS), elds, s, keys, tmp, \
-                           src16, bstart, plan, err, (uint32_t)km.neg, (uint32_t)km.pos, list2, list2_count, slot_count, slot_cap, only_route); \
+                           src16, bstart, plan, err, (uint32_t)km.neg, (uint32_t)km.pos, list2, list2_count, slot_count, slot_cap); \
     } while (0)
                 if (src16) { if (mapped) RDST_EXPAND(true, true); else RDST_EXPAND(false, true); }
                 else { if (mapped) RDST_EXPAND(true, false); else RDST_EXPAND(false, false); }
@@ -4274,21 +4438,30 @@ int launch_local_sort(K* keys, K* tmp, const uint32_t* bstart, const Plan* plan,
     if constexpr (sizeof(K) == 8) {
         if (g_tuning.count_sort) {
             constexpr size_t wlds = wide_lds_bytes();
-            if (g_tuning.wide2) {  // two 512-thread blocks per CU
+            if (g_tuning.wide2 && g_tuning.wide3) {  // two 1024-thread blocks per CU, a third fewer LDS instructions than wide2
+                constexpr size_t w3 = wide3_lds_bytes();
+                if (mapped) {
+                    if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_wide3_sort_kernel<true>), w3)) return rc;
+                    hipLaunchKernelGGL((local_wide3_sort_kernel<true>), dim3(H16_BINS), dim3(WIDE3_THREADS), w3, s, keys, tmp, bstart, plan, err, (uint64_t)km.neg, (uint64_t)km.pos, list, list_count, src_slots, slot_count, slot_cap);
+                } else {
+                    if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_wide3_sort_kernel<false>), w3)) return rc;
+                    hipLaunchKernelGGL((local_wide3_sort_kernel<false>), dim3(H16_BINS), dim3(WIDE3_THREADS), w3, s, keys, tmp, bstart, plan, err, (uint64_t)km.neg, (uint64_t)km.pos, list, list_count, src_slots, slot_count, slot_cap);
+                }
+            } else if (g_tuning.wide2) {  // the same with half the prefix table and every per-key state re-read (A/B, tests)
                 constexpr size_t w2 = wide2_lds_bytes();
                 if (mapped) {
                     if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_wide2_sort_kernel<true>), w2)) return rc;
-                    hipLaunchKernelGGL((local_wide2_sort_kernel<true>), dim3(H16_BINS), dim3(WIDE2_THREADS), w2, s, keys, tmp, bstart, plan, err, (uint64_t)km.neg, (uint64_t)km.pos, list, list_count, src_slots, slot_count, slot_cap, only_route);
+                    hipLaunchKernelGGL((local_wide2_sort_kernel<true>), dim3(H16_BINS), dim3(WIDE2_THREADS), w2, s, keys, tmp, bstart, plan, err, (uint64_t)km.neg, (uint64_t)km.pos, list, list_count, src_slots, slot_count, slot_cap);
                 } else {
                     if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_wide2_sort_kernel<false>), w2)) return rc;
-                    hipLaunchKernelGGL((local_wide2_sort_kernel<false>), dim3(H16_BINS), dim3(WIDE2_THREADS), w2, s, keys, tmp, bstart, plan, err, (uint64_t)km.neg, (uint64_t)km.pos, list, list_count, src_slots, slot_count, slot_cap, only_route);
+                    hipLaunchKernelGGL((local_wide2_sort_kernel<false>), dim3(H16_BINS), dim3(WIDE2_THREADS), w2, s, keys, tmp, bstart, plan, err, (uint64_t)km.neg, (uint64_t)km.pos, list, list_count, src_slots, slot_count, slot_cap);
                 }
             } else if (mapped) {
                 if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_wide_sort_kernel<true>), wlds)) return rc;
-                hipLaunchKernelGGL((local_wide_sort_kernel<true>), dim3(H16_BINS), dim3(WIDE_THREADS), wlds, s, keys, tmp, bstart, plan, err, (uint64_t)km.neg, (uint64_t)km.pos, list, list_count, only_route);
+                hipLaunchKernelGGL((local_wide_sort_kernel<true>), dim3(H16_BINS), dim3(WIDE_THREADS), wlds, s, keys, tmp, bstart, plan, err, (uint64_t)km.neg, (uint64_t)km.pos, list, list_count);
             } else {
                 if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_wide_sort_kernel<false>), wlds)) return rc;
-                hipLaunchKernelGGL((local_wide_sort_kernel<false>), dim3(H16_BINS), dim3(WIDE_THREADS), wlds, s, keys, tmp, bstart, plan, err, (uint64_t)km.neg, (uint64_t)km.pos, list, list_count, only_route);
+                hipLaunchKernelGGL((local_wide_sort_kernel<false>), dim3(H16_BINS), dim3(WIDE_THREADS), wlds, s, keys, tmp, bstart, plan, err, (uint64_t)km.neg, (uint64_t)km.pos, list, list_count);
             }
             HIP_TRY(hipGetLastError());
             listed = true;
@@ -4298,10 +4471,10 @@ int launch_local_sort(K* keys, K* tmp, const uint32_t* bstart, const Plan* plan,
     const uint32_t* wl = listed ? list : nullptr;
     if (mapped) {
         if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_sort_kernel<K, NW, KPT, true>), lds)) return rc;
-        hipLaunchKernelGGL((local_sort_kernel<K, NW, KPT, true>), grid, dim3(NW * 64), lds, s, keys, tmp, bstart, plan, err, (K)km.neg, (K)km.pos, flags, wl, list_count, src16, slot_count, slot_cap, src_slots, only_route);
+        hipLaunchKernelGGL((local_sort_kernel<K, NW, KPT, true>), grid, dim3(NW * 64), lds, s, keys, tmp, bstart, plan, err, (K)km.neg, (K)km.pos, flags, wl, list_count, src16, slot_count, slot_cap, src_slots);
     } else {
         if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&local_sort_kernel<K, NW, KPT, false>), lds)) return rc;
-        hipLaunchKernelGGL((local_sort_kernel<K, NW, KPT, false>), grid, dim3(NW * 64), lds, s, keys, tmp, bstart, plan, err, (K)km.neg, (K)km.pos, flags, wl, list_count, src16, slot_count, slot_cap, src_slots, only_route);
+        hipLaunchKernelGGL((local_sort_kernel<K, NW, KPT, false>), grid, dim3(NW * 64), lds, s, keys, tmp, bstart, plan, err, (K)km.neg, (K)km.pos, flags, wl, list_count, src16, slot_count, slot_cap, src_slots);
     }
     HIP_TRY(hipGetLastError());
     return RDST_OK;
@@ -4461,7 +4634,7 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
         r.cfg = cfg0;
         r.try_atomic = !lean && whole_sort && atomic_eligible(n, sizeof(K), r.cfg);
         // 8-byte keys: the fallback's passes run as persistent blocks of shape 5 (eight skipped passes of one block per tile cost 0.5 ms per 10^9 keys)
-        if (r.try_atomic && sizeof(K) == 8 && g_tuning.persist_fallback && !g_tuning.side_stream && g_tuning.pass_cfg < 0) r.cfg = 5;
+        if (r.try_atomic && sizeof(K) == 8 && g_tuning.persist_fallback && g_tuning.pass_cfg < 0) r.cfg = 5;
         // Behind a failed atomic route (an area or a slot overflowed) the hybrid route is tried next — exact counts, any bucket
         // the local sort takes — and the LSD route last.  One launch sequence serves all three: every kernel looks at the plan.
         const bool halves_cfg = g_tuning.halves && g_tuning.count_sort && halves_possible<K>(r.cfg, n);
@@ -4533,8 +4706,6 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     const bool pair = g_tuning.chains && LEVELS >= 2 && level_hi > level_lo + 1;
     unsigned long long* hpair = reinterpret_cast<unsigned long long*>(ws + L.off_hpair);
     Plan* plan = reinterpret_cast<Plan*>(ws + L.off_plan);
-    hipStream_t fs = s;   // the stream the fallback routes' launches go to (the side stream once forked)
-    bool forked = false;
     // K1h + the route decision, launched twice behind a tried atomic route: before the MSD passes (they run only if the sample
     // flagged the keys; the MSD passes then take their exact form for the hybrid route) and after them (what is left)
     auto count_and_route = [&](uint32_t pre_launch, bool sample_first, hipStream_t cs) -> int {
@@ -4642,34 +4813,9 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
             hipLaunchKernelGGL(msd_finish_kernel, dim3(1), dim3(1024), 0, s, fa);
             HIP_TRY(hipGetLastError());
             if ((rc = prof_mark(*D, s, RDST_STAGE_ROUTE))) return rc;
-            if (g_tuning.side_stream) {
-                // The route is decided.  K4 of the atomic route follows on the caller's stream; everything the OTHER routes need —
-                // K1h, the route decision, the clears, K1, K2, the K3 passes, their K4, the giants, the copy-back: ~20 launches
-                // that return at once on the good path — goes to the library's side stream, beside K4 instead of before it
-                // (0.14 ms of 4.4 per 10^9 u32 keys, and the K3 passes need no persistent form to be cheap to skip).
-                if (!D->side_stream) {
-                    HIP_TRY(hipStreamCreateWithFlags(&D->side_stream, hipStreamNonBlocking));
-                    HIP_TRY(hipEventCreateWithFlags(&D->ev_fork, hipEventDisableTiming));
-                    HIP_TRY(hipEventCreateWithFlags(&D->ev_join, hipEventDisableTiming));
-                }
-                HIP_TRY(hipEventRecord(D->ev_fork, s));
-                rc = launch_local_sort<K>(keys, tmp, reinterpret_cast<const uint32_t*>(ws + L.off_bstart), plan, D->err_dev, km,
-                                          reinterpret_cast<uint32_t*>(ws + L.off_fblist), reinterpret_cast<uint32_t*>(ws + L.off_err) + 3,
-                                          sizeof(K) == 4 ? reinterpret_cast<const uint16_t*>(ws + L.off_halves) : nullptr, D->cus, s,
-                                          reinterpret_cast<const uint32_t*>(ws + L.off_cursor_b), L.slot_cap,
-                                          sizeof(K) == 8 ? reinterpret_cast<const K*>(ws + L.off_halves) : nullptr,
-                                          reinterpret_cast<uint32_t*>(ws + L.off_fblist2), reinterpret_cast<uint32_t*>(ws + L.off_err) + 5,
-                                          nullptr, ROUTE_ATOMIC + 1u);
-                if (rc) return rc;
-                if ((rc = prof_mark(*D, s, RDST_STAGE_LOCAL))) return rc;
-                HIP_TRY(hipStreamWaitEvent(D->side_stream, D->ev_fork, 0));
-                fs = D->side_stream;
-                forked = true;
-                if ((rc = prof_mark(*D, fs, RDST_STAGE_NONE))) return rc;
-            }
             if (!try_hybrid) {  // the LSD route's status rows, if the route fell that way
                 const uint64_t vecs = level_rows * LEVELS / 16;
-                hipLaunchKernelGGL(clear_unless_hybrid_kernel, dim3((uint32_t)D->cus * 4), dim3(256), 0, fs, plan, reinterpret_cast<uint4*>(ws + L.off_status),
+                hipLaunchKernelGGL(clear_unless_hybrid_kernel, dim3((uint32_t)D->cus * 4), dim3(256), 0, s, plan, reinterpret_cast<uint4*>(ws + L.off_status),
                                    vecs, reinterpret_cast<uint4*>(ws + L.off_status_near), vecs, 0u);
                 HIP_TRY(hipGetLastError());
             }
@@ -4677,26 +4823,26 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     }
     if constexpr (!HAS_V && (sizeof(K) == 4 || sizeof(K) == 8)) {
         if (try_hybrid) {
-            if ((rc = count_and_route(0u, !try_atomic, fs))) return rc;
+            if ((rc = count_and_route(0u, !try_atomic, s))) return rc;
             if (split_clear) {
                 const uint64_t vecs = level_rows * (LEVELS - 2) / 16;  // rows are multiples of 1 KiB
-                hipLaunchKernelGGL(clear_unless_hybrid_kernel, dim3((uint32_t)D->cus * 4), dim3(256), 0, fs, plan,
+                hipLaunchKernelGGL(clear_unless_hybrid_kernel, dim3((uint32_t)D->cus * 4), dim3(256), 0, s, plan,
                                    reinterpret_cast<uint4*>(ws + L.off_status), vecs, reinterpret_cast<uint4*>(ws + L.off_status_near), vecs, 0u);
                 HIP_TRY(hipGetLastError());
             } else if (try_atomic) {  // nothing was cleared up front: every level's rows, unless the atomic route took the sort
                 const uint64_t vecs = level_rows * LEVELS / 16;
-                hipLaunchKernelGGL(clear_unless_hybrid_kernel, dim3((uint32_t)D->cus * 4), dim3(256), 0, fs, plan,
+                hipLaunchKernelGGL(clear_unless_hybrid_kernel, dim3((uint32_t)D->cus * 4), dim3(256), 0, s, plan,
                                    reinterpret_cast<uint4*>(ws + L.off_status), vecs, reinterpret_cast<uint4*>(ws + L.off_status_near), vecs, 1u);
                 HIP_TRY(hipGetLastError());
             }
-            if ((rc = prof_mark(*D, fs, RDST_STAGE_ROUTE))) return rc;
+            if ((rc = prof_mark(*D, s, RDST_STAGE_ROUTE))) return rc;
         }
     }
     // a single pass (the parity hook, the sharded route's split) counts its own level only: one LDS atomic per key
-    if (LEVELS > 1 && level_hi == level_lo + 1) rc = launch_hist<K, 1>(keys, n, (uint32_t)blocks, km, hpos, hpair, false, inversion, nullptr, fs, &piece, (int)level_lo);
-    else rc = launch_hist<K, LEVELS>(keys, n, (uint32_t)blocks, km, hpos, hpair, pair, inversion, (try_hybrid || try_atomic) ? plan : nullptr, fs, &piece);
+    if (LEVELS > 1 && level_hi == level_lo + 1) rc = launch_hist<K, 1>(keys, n, (uint32_t)blocks, km, hpos, hpair, false, inversion, nullptr, s, &piece, (int)level_lo);
+    else rc = launch_hist<K, LEVELS>(keys, n, (uint32_t)blocks, km, hpos, hpair, pair, inversion, (try_hybrid || try_atomic) ? plan : nullptr, s, &piece);
     if (rc) return rc;
-    if ((rc = prof_mark(*D, fs, RDST_STAGE_HIST))) return rc;
+    if ((rc = prof_mark(*D, s, RDST_STAGE_HIST))) return rc;
     ScanArgs sa{};
     sa.hpos = hpos;
     sa.hpair = pair ? hpair : nullptr;
@@ -4717,22 +4863,21 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     sa.tile = L.tile;
     sa.use_chains = g_tuning.chains ? 1u : 0u;
     sa.halves = halves ? 1u : 0u;
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(256 * SCAN_GROUPS), 0, fs, sa);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(256 * SCAN_GROUPS), 0, s, sa);
     HIP_TRY(hipGetLastError());
-    if ((rc = prof_mark(*D, fs, RDST_STAGE_SCAN))) return rc;
+    if ((rc = prof_mark(*D, s, RDST_STAGE_SCAN))) return rc;
     for (uint32_t level = level_lo; level < level_hi; ++level) {
-        if constexpr (HAS_V) rc = launch_pass_pairs<K, V>(keys, tmp, vals, vtmp, n, (int)level, L, ws, km, D->cus, fs);
-        else rc = launch_pass<K>(cfg, keys, tmp, n, (int)level, L, ws, km, D->cus, fs,
+        if constexpr (HAS_V) rc = launch_pass_pairs<K, V>(keys, tmp, vals, vtmp, n, (int)level, L, ws, km, D->cus, s);
+        else rc = launch_pass<K>(cfg, keys, tmp, n, (int)level, L, ws, km, D->cus, s,
                                  halves && level + 1 == (uint32_t)LEVELS ? reinterpret_cast<uint16_t*>(ws + L.off_halves) : nullptr,
-                                 try_atomic && g_tuning.persist_fallback && !forked);
+                                 try_atomic && g_tuning.persist_fallback);
         if (rc) return rc;
-        if ((rc = prof_mark(*D, fs, RDST_STAGE_PASS | (level << 8)))) return rc;
+        if ((rc = prof_mark(*D, s, RDST_STAGE_PASS | (level << 8)))) return rc;
     }
     if constexpr (!HAS_V && (sizeof(K) == 4 || sizeof(K) == 8)) {
-        if (try_hybrid || (try_atomic && !forked)) {
+        if (try_hybrid || try_atomic) {
             // one K4 for both routes: the atomic route's buckets lie in the slots, the hybrid route's at their final place
-            // (4-byte keys: as low halves, in the same region of the workspace either way).  Forked: this launch serves the
-            // hybrid route only — the atomic route's K4 ran on the caller's stream, beside all of this.
+            // (4-byte keys: as low halves, in the same region of the workspace either way)
             const bool from16 = sizeof(K) == 4 && (try_atomic || halves);
             GiantArgs ga{};
             ga.glist = reinterpret_cast<uint32_t*>(ws + L.off_glist);
@@ -4742,13 +4887,13 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
             ga.recs = reinterpret_cast<GiantItem*>(ws + L.off_gsplit);
             rc = launch_local_sort<K>(keys, tmp, reinterpret_cast<const uint32_t*>(ws + L.off_bstart), plan, D->err_dev, km,
                                       reinterpret_cast<uint32_t*>(ws + L.off_fblist), reinterpret_cast<uint32_t*>(ws + L.off_err) + 3,
-                                      from16 ? reinterpret_cast<const uint16_t*>(ws + L.off_halves) : nullptr, D->cus, fs,
+                                      from16 ? reinterpret_cast<const uint16_t*>(ws + L.off_halves) : nullptr, D->cus, s,
                                       try_atomic ? reinterpret_cast<const uint32_t*>(ws + L.off_cursor_b) : nullptr, L.slot_cap,
                                       try_atomic && sizeof(K) == 8 ? reinterpret_cast<const K*>(ws + L.off_halves) : nullptr,
                                       reinterpret_cast<uint32_t*>(ws + L.off_fblist2), reinterpret_cast<uint32_t*>(ws + L.off_err) + 5,
-                                      giants ? &ga : nullptr, forked ? ROUTE_HYBRID + 1u : 0u);
+                                      giants ? &ga : nullptr);
             if (rc) return rc;
-            if ((rc = prof_mark(*D, fs, RDST_STAGE_LOCAL))) return rc;
+            if ((rc = prof_mark(*D, s, RDST_STAGE_LOCAL))) return rc;
         }
     }
     if (copy_back) {
@@ -4760,9 +4905,9 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
         const Plan* plan = reinterpret_cast<const Plan*>(ws + L.off_plan);
         constexpr int VEC = 16 / sizeof(K);
         if (aligned)
-            hipLaunchKernelGGL((copyback_kernel<K, VEC>), dim3((uint32_t)cblocks), dim3(256), 0, fs, keys, tmp, n, plan);
+            hipLaunchKernelGGL((copyback_kernel<K, VEC>), dim3((uint32_t)cblocks), dim3(256), 0, s, keys, tmp, n, plan);
         else
-            hipLaunchKernelGGL((copyback_kernel<K, 1>), dim3((uint32_t)cblocks), dim3(256), 0, fs, keys, tmp, n, plan);
+            hipLaunchKernelGGL((copyback_kernel<K, 1>), dim3((uint32_t)cblocks), dim3(256), 0, s, keys, tmp, n, plan);
         HIP_TRY(hipGetLastError());
         if constexpr (HAS_V) {
             const bool valigned = ((reinterpret_cast<uintptr_t>(vals) | reinterpret_cast<uintptr_t>(vtmp)) & 15u) == 0;
@@ -4771,16 +4916,12 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
             if (vblocks < 1) vblocks = 1;
             constexpr int VVEC = 16 / sizeof(V);
             if (valigned)
-                hipLaunchKernelGGL((copyback_kernel<V, VVEC>), dim3((uint32_t)vblocks), dim3(256), 0, fs, vals, vtmp, n, plan);
+                hipLaunchKernelGGL((copyback_kernel<V, VVEC>), dim3((uint32_t)vblocks), dim3(256), 0, s, vals, vtmp, n, plan);
             else
-                hipLaunchKernelGGL((copyback_kernel<V, 1>), dim3((uint32_t)vblocks), dim3(256), 0, fs, vals, vtmp, n, plan);
+                hipLaunchKernelGGL((copyback_kernel<V, 1>), dim3((uint32_t)vblocks), dim3(256), 0, s, vals, vtmp, n, plan);
             HIP_TRY(hipGetLastError());
         }
-        if ((rc = prof_mark(*D, fs, RDST_STAGE_COPYBACK))) return rc;
-    }
-    if (forked) {  // join: the caller's stream continues when the side stream is through
-        HIP_TRY(hipEventRecord(D->ev_join, fs));
-        HIP_TRY(hipStreamWaitEvent(s, D->ev_join, 0));
+        if ((rc = prof_mark(*D, s, RDST_STAGE_COPYBACK))) return rc;
     }
     if (layout_out) *layout_out = L;
     if (ws_out) *ws_out = ws;
@@ -5010,6 +5151,7 @@ int rdst_hip_set_hybrid(int enabled, uint64_t min_len) {
     g_tuning.halves = enabled != 3;      // 3: counting K4 reading whole keys (no 16-bit hand-off) (A/B, tests)
     g_tuning.presample = enabled != 5;   // 5: no sample before K1h: every hybrid-eligible sort counts all its keys' prefixes first (tests)
     g_tuning.wide2 = enabled != 6;       // 6: 8-byte keys with the one-block-per-CU form of K4 (A/B, tests)
+    g_tuning.wide3 = enabled != 15;      // 15: the default with the second form of the 8-byte K4 (local_wide2_sort_kernel) (A/B, tests)
     g_tuning.atomic_route = enabled == 1 || enabled == 8;  // 1: the default (4- and 8-byte keys try the atomic route first); 2..7: the K1h hybrid route for every key width (7: with the default forms of K4)
     g_tuning.exact_msd = enabled != 12;    // 12: the default without the exact form of the MSD passes (the hybrid route's passes are K3's) (A/B, tests)
     g_tuning.atomic_route = g_tuning.atomic_route || enabled == 12;
@@ -5019,10 +5161,8 @@ int rdst_hip_set_hybrid(int enabled, uint64_t min_len) {
     g_tuning.atomic_route = g_tuning.atomic_route || enabled == 10;
     g_tuning.expand = enabled != 9;        // 9: the K1h hybrid route without the expanding K4 (buckets up to one tile; refused buckets to the ranked kernel) (A/B, tests)
     g_tuning.atomic_wide = enabled != 8;   // 8: the atomic route for 4-byte keys only, 8-byte keys on the K1h hybrid route (A/B, tests)
-    g_tuning.side_stream = enabled != 13;  // 13: the default with every launch on the caller's stream (the fallback's K3 passes in their persistent form) (A/B, tests)
-    g_tuning.atomic_route = g_tuning.atomic_route || enabled == 13;
     g_tuning.predict = enabled != 14;      // 14: the default without the sample's prediction of the LSD route (A/B, tests)
-    g_tuning.atomic_route = g_tuning.atomic_route || enabled == 14;
+    g_tuning.atomic_route = g_tuning.atomic_route || enabled == 14 || enabled == 15;
     g_tuning.hybrid_min_len = min_len ? min_len : (1ull << 28);
     return RDST_OK;
 }
@@ -5182,12 +5322,10 @@ int rdst_hip_profile_run(int run, float* out_ms, uint32_t capacity, uint32_t* n_
     if (run < 0 || run >= (int)D->prof_runs.size()) return fail(RDST_ERR_ARG, "no such profiled run");
     const auto r = D->prof_runs[run];
     if (r.count < 2) return RDST_OK;
-    for (uint32_t i = 0; i < r.count; ++i) HIP_TRY(hipEventSynchronize(D->prof_events[r.begin + i]));  // (two streams: the last event need not be the last to complete)
+    HIP_TRY(hipEventSynchronize(D->prof_events[r.begin + r.count - 1]));
     const uint32_t n = r.count - 1;
-    for (uint32_t i = 0; i < n && i < capacity; ++i) {
-        if ((D->prof_kinds[r.begin + i] & 0xFFu) == RDST_STAGE_NONE) { out_ms[i] = 0.0f; continue; }  // the two events lie on different streams
+    for (uint32_t i = 0; i < n && i < capacity; ++i)
         HIP_TRY(hipEventElapsedTime(&out_ms[i], D->prof_events[r.begin + i], D->prof_events[r.begin + i + 1]));
-    }
     *n_out = n < capacity ? n : capacity;
     return RDST_OK;
 }

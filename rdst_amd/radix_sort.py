@@ -465,8 +465,6 @@ def profile_run(run: int, levels: int):
     out = {"clear": 0.0, "histogram": 0.0, "scan": 0.0, "passes": [], "copy_back": 0.0, "stages": []}
     for i in range(n.value):
         code, level = kinds[i] & 0xFF, (kinds[i] >> 8) & 0xFF
-        if code == 0xFF:   # no stage: the events on its two sides lie on different streams (the fallback routes' side stream)
-            continue
         name = STAGE_NAMES.get(code, f"stage{code}")
         ms = float(buf[i])
         out["stages"].append((name, level if name == "pass" else None, ms))
