@@ -2562,58 +2562,95 @@ __global__ __launch_bounds__(NWAVES * 64, (sizeof(K) <= 4 ? 2 : 1) * NWAVES / 4)
 // then leaves the bucket untouched and queues it for the generic kernel above.
 constexpr int COUNT_TILE = local_tile(4);  // the route's bucket bound for 4-byte keys
 constexpr size_t count_lds_bytes() { return 32768 + 16384 + 128; }
-static_assert(2 * (size_t)COUNT_TILE <= 32768 + 16384, "the output staging aliases the counter and prefix tables");
+static_assert(2 * ((size_t)COUNT_TILE + 4) <= 32768 + 16384, "the output staging (shifted by up to three keys) aliases the counter and prefix tables");
 
 __device__ __forceinline__ uint32_t nibble_sum(uint32_t x, uint32_t acc) {
     const uint32_t t = (x & 0x0F0F0F0Fu) + ((x >> 4) & 0x0F0F0F0Fu);
     return __builtin_amdgcn_sad_u8(t, 0u, acc);  // acc + the four byte sums
 }
 
+// The kernel is bound by vector-instruction issue, not by memory or LDS (round 3: 46.7 VALU instructions per key = 1.19 of its
+// 1.37 ms at one wave-instruction per clock and CU), so its body exists in four forms chosen per bucket, block-uniformly:
+//   FAST   the bucket holds at least COUNT_SAFE keys per thread (uniform 10^9-key sorts: always — the mean is 7.5 sigma
+//          above): the first COUNT_SAFE rounds of every phase run without the `idx < cnt` predicate (-8 instructions per key)
+//   VEC    (atomic route: the halves lie in a slot, 128-byte aligned) the halves arrive as four 16-byte vectors and one
+//          16-bit load per thread instead of 33 16-bit loads with their address arithmetic and clamps
+// and the sorted bucket leaves in 16-byte stores of four keys (the staging is shifted by the destination's misalignment, so that
+// an aligned LDS read of four halves is an aligned global store of four keys): 9 store rounds instead of 33.
+constexpr int COUNT_SAFE = 24;  // rounds (keys per thread) that need no predicate in a FAST bucket
+
 // FROM16: the bucket arrives as the low halves of the mapped keys (pass L-1 stored only those, see OUT16 of K3)
-template <int BLOCK, bool MAPPED, bool FROM16>
-__global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 8 : 6) void local_count_sort_kernel(
-    uint32_t* __restrict__ buf_keys, uint32_t* __restrict__ buf_tmp, const uint16_t* __restrict__ src16, const uint32_t* __restrict__ bstart,
-    const Plan* __restrict__ plan, uint32_t* __restrict__ err, uint32_t neg, uint32_t pos, uint32_t* __restrict__ list,
-    uint32_t* __restrict__ list_count, const uint32_t* __restrict__ slot_count /* ROUTE_ATOMIC: bucket b's halves lie in slot b (slot_cap
-    entries) of src16 and number slot_count[b]; NULL: they lie at their final place, bstart */, uint32_t slot_cap) {
+template <int BLOCK, bool MAPPED, bool FROM16, bool FAST, bool VEC>
+__device__ __forceinline__ void count_sort_bucket(uint32_t* __restrict__ buf, const uint16_t* __restrict__ src16, uint32_t soff, uint32_t start, uint32_t cnt,
+                                                  uint32_t bucket, const Plan* __restrict__ plan, uint32_t neg, uint32_t pos, uint32_t* __restrict__ list,
+                                                  uint32_t* __restrict__ list_count, unsigned char* smem) {
     constexpr int MAXR = (COUNT_TILE + BLOCK - 1) / BLOCK;
     constexpr int VPT = H16_BINS / BLOCK, WPT = VPT / 8;  // values / counter words per thread
     constexpr int LOG_VPT = BLOCK == 1024 ? 6 : (BLOCK == 512 ? 7 : 8);
     static_assert((1 << LOG_VPT) == VPT, "block size");
-    if (!plan->local_sort) return;
-    if (plan->route != ROUTE_ATOMIC) slot_count = nullptr;  // the hybrid route's buckets lie at their final place (src16: position for position)
-    uint32_t* __restrict__ buf = plan->result_in_tmp ? buf_tmp : buf_keys;
-    const uint32_t bucket = blockIdx.x;
-    const uint32_t start = bstart[bucket], cnt = slot_count ? slot_count[bucket] : bstart[bucket + 1] - start;
-    const uint32_t soff = slot_count ? bucket * slot_cap : start;  // where the bucket's keys lie now
+    static_assert(!VEC || (FROM16 && MAXR == 33 && BLOCK == 512), "vector loads: four vectors of eight halves and one half per thread");
+    static_assert(COUNT_SAFE % 8 == 0 && COUNT_SAFE < MAXR, "whole vectors");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (cnt <= 1) {
-        if constexpr (FROM16) {  // the key exists only as its low half: put it back together
-            if (cnt == 1 && tid == 0) {
-                const uint32_t m = (bucket_prefix16(plan, bucket) << 16) | (uint32_t)src16[soff];
-                buf[start] = MAPPED ? unmap_key<uint32_t>(m, neg, pos) : m;
-            }
-        }
-        return;
-    }
-    if (cnt >= GIANT_MIN && plan->giants) return;  // the giant kernels' (route_kernel listed it)
-    if (cnt > (uint32_t)COUNT_TILE || plan->low_dups) {  // more than this kernel stages, or (the sample says) low halves its 4-bit counters cannot count: handed on
-        if (tid == 0) list[atomicAdd(list_count, 1u)] = bucket;
-        return;
-    }
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* cnt4 = reinterpret_cast<uint32_t*>(smem);                    // [WPT][BLOCK] words of eight 4-bit counters
     uint16_t* prefix = reinterpret_cast<uint16_t*>(smem + 32768);          // [WPT][BLOCK] keys below the word's first value
-    uint16_t* out16 = reinterpret_cast<uint16_t*>(smem);                   // [cnt] sorted low halves (aliases both, later)
+    uint16_t* out16 = reinterpret_cast<uint16_t*>(smem);                   // [cnt + 3] sorted low halves (aliases both, later)
     uint32_t* s_wsum = reinterpret_cast<uint32_t*>(smem + 32768 + 16384);  // [16] wave sums, [16] overflow flag
+    // key i of this thread is element idx_of(i) of the bucket (any assignment will do: the order inside a bucket means nothing
+    // yet).  Either way idx_of grows with i, so a thread's valid keys are its first `nvalid`: ONE register holds every predicate
+    // of every phase.  (Each phase compares against its own opaque copy: left alone, the compiler computes the 33 lane masks once
+    // and keeps them in 66 scalar registers across all phases — which, with everything else that is live, it then spills.)
+    auto idx_of = [&](int i) -> uint32_t {
+        if constexpr (VEC) return i < 32 ? 8u * ((uint32_t)tid + (uint32_t)(i >> 3) * BLOCK) + (uint32_t)(i & 7) : 32u * BLOCK + (uint32_t)tid;
+        else return (uint32_t)tid + (uint32_t)i * BLOCK;
+    };
+    uint32_t nvalid = 0;
+    if constexpr (VEC) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t v0 = 8u * ((uint32_t)tid + (uint32_t)j * BLOCK);
+            nvalid += cnt > v0 ? (cnt - v0 < 8u ? cnt - v0 : 8u) : 0u;
+        }
+        nvalid += 32u * BLOCK + (uint32_t)tid < cnt ? 1u : 0u;
+    } else {
+        nvalid = cnt > (uint32_t)tid ? (cnt - (uint32_t)tid + BLOCK - 1u) / BLOCK : 0u;
+    }
+#define RDST_K4_PHASE() uint32_t nv_ = nvalid; asm volatile("" : "+v"(nv_))
+#define RDST_K4_VALID(i) ((FAST && (i) < COUNT_SAFE) || (uint32_t)(i) < nv_)
+    // Without predicates the unrolled rounds of a phase are one basic block each, and the compiler, left alone, carries every
+    // round's table address and shift from the count phase over to the place phase (66 registers it does not have: 230 dwords of
+    // spills) instead of recomputing three instructions: the keys are made opaque between the phases.
+#define RDST_K4_FENCE(i) do { if (((i) & 3) == 3 || (i) == MAXR - 1) { _Pragma("unroll") for (int f_ = (i) - ((i) & 3); f_ <= (i); ++f_) asm volatile("" : "+v"(kv[f_])); } } while (0)  // (a group of rounds is pinned where it is computed: left alone, every round's LDS reads are issued first and their results spilled)
+#define RDST_K4_OPAQUE() do { _Pragma("unroll") for (int i_ = 0; i_ < MAXR; ++i_) asm volatile("" : "+v"(kv[i_])); } while (0)
     __builtin_amdgcn_s_setprio(RDST_PRIO_LOAD);
     uint32_t kv[MAXR];
+    if constexpr (VEC) {
+        const uint4* vsrc = reinterpret_cast<const uint4*>(src16 + soff);  // (slot_cap is a multiple of 64 halves, the halves array 256-byte aligned)
+        uint4 q[4];
 #pragma unroll
-    for (int i = 0; i < MAXR; ++i) {
-        const uint32_t idx = (uint32_t)tid + i * BLOCK;
-        const uint32_t at = idx < cnt ? idx : cnt - 1;
-        if constexpr (FROM16) kv[i] = src16[soff + at];
-        else kv[i] = buf[start + at];
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t vi = (uint32_t)tid + j * BLOCK;
+            if ((FAST && j < COUNT_SAFE / 8) || 8u * vi < cnt) q[j] = vsrc[vi];  // (a vector that starts inside the bucket lies inside the slot: its capacity is a multiple of 64)
+            else q[j] = make_uint4(0, 0, 0, 0);
+        }
+        kv[32] = 32u * BLOCK + (uint32_t)tid < cnt ? (uint32_t)src16[soff + 32u * BLOCK + (uint32_t)tid] : 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t d[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                kv[8 * j + 2 * e] = d[e] & 0xFFFFu;
+                kv[8 * j + 2 * e + 1] = d[e] >> 16;
+            }
+        }
+    } else {
+        RDST_K4_PHASE();
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i) {
+            const uint32_t idx = idx_of(i);
+            const uint32_t at = RDST_K4_VALID(i) ? idx : cnt - 1;
+            if constexpr (FROM16) kv[i] = src16[soff + at];
+            else kv[i] = buf[start + at];
+        }
     }
 #pragma unroll
     for (int k = 0; k < WPT; ++k) cnt4[k * BLOCK + tid] = 0;
@@ -2622,10 +2659,11 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 8 : 6) void local_count_sort
     __builtin_amdgcn_s_setprio(0);
     auto word_of = [](uint32_t v) -> uint32_t { return ((v >> 3) & (uint32_t)(WPT - 1)) * BLOCK + (v >> LOG_VPT); };
     bool over = false;
+    {
+    RDST_K4_PHASE();
 #pragma unroll
     for (int i = 0; i < MAXR; ++i) {
-        const uint32_t idx = (uint32_t)tid + i * BLOCK;
-        if (idx < cnt) {
+        if (RDST_K4_VALID(i)) {
             const uint32_t v = FROM16 ? kv[i] : ((MAPPED ? map_key<uint32_t>(kv[i], neg, pos) : kv[i]) & 0xFFFFu);
             const uint32_t sh = (v & 7u) * 4u;
             const uint32_t old = atomicAdd(&cnt4[word_of(v)], 1u << sh);
@@ -2633,29 +2671,32 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 8 : 6) void local_count_sort
             over |= mine == 15u;
             kv[i] = v | (mine << 16);
         }
+        RDST_K4_FENCE(i);
+    }
     }
     if (over) s_wsum[16] = 1;
     __syncthreads();
     if (s_wsum[16]) {  // block-uniform: a value 16 times
         // one value only (the bimodal bench input: every bucket of the shifted half)?  Then the bucket is written at once ...
         bool differ = false;
-        const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)kv[0]) & 0xFFFFu;  // (kv: value | index << 16 by now)
+        uint32_t mine_first = 0;
+        bool have = false;
+        RDST_K4_PHASE();
 #pragma unroll
         for (int i = 0; i < MAXR; ++i) {
-            const uint32_t idx = (uint32_t)tid + i * BLOCK;
-            if (idx < cnt) differ |= (kv[i] & 0xFFFFu) != first;
-        }
-        if (tid == 0) s_wsum[17] = first;
-        const int any = __syncthreads_or((int)differ);       // every wave of one value ...
-        const bool agree = first == s_wsum[17] || (uint32_t)(tid & ~63) >= cnt;
-        if (!any && !__syncthreads_or((int)!agree)) {       // ... and the same one
-            const uint32_t m = (bucket_prefix16(plan, bucket) << 16) | first;
-            const uint32_t out = MAPPED ? unmap_key<uint32_t>(m, neg, pos) : m;
-#pragma unroll
-            for (int i = 0; i < MAXR; ++i) {
-                const uint32_t idx = (uint32_t)tid + i * BLOCK;
-                if (idx < cnt) buf[start + idx] = out;
+            if (RDST_K4_VALID(i)) {
+                if (!have) { mine_first = kv[i] & 0xFFFFu; have = true; }
+                differ |= (kv[i] & 0xFFFFu) != mine_first;
             }
+        }
+        // (kv: value | index << 16 by now; element 0 of the bucket is key 0 of thread 0 in both assignments)
+        if (tid == 0) s_wsum[17] = mine_first;
+        const int any = __syncthreads_or((int)differ);       // every thread of one value ...
+        const bool agree = !have || mine_first == s_wsum[17];
+        if (!any && !__syncthreads_or((int)!agree)) {       // ... and the same one
+            const uint32_t m = (bucket_prefix16(plan, bucket) << 16) | s_wsum[17];
+            const uint32_t out = MAPPED ? unmap_key<uint32_t>(m, neg, pos) : m;
+            for (uint32_t idx = (uint32_t)tid; idx < cnt; idx += BLOCK) buf[start + idx] = out;
             return;
         }
         // ... else it stays as it is, for the next kernel
@@ -2686,35 +2727,107 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 8 : 6) void local_count_sort
         for (int k = 0; k < WPT; ++k) prefix[k * BLOCK + tid] = (uint16_t)(base + pre[k]);
     }
     __syncthreads();
+    // the staging is shifted by the destination's misalignment (in keys, 0..3): LDS quad q then is the 16-byte aligned global quad q
+    uint32_t* tdst = buf + start;
+    const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(tdst) >> 2) & 3u;
+    {
+    RDST_K4_PHASE();
+    RDST_K4_OPAQUE();
 #pragma unroll
     for (int i = 0; i < MAXR; ++i) {
-        const uint32_t idx = (uint32_t)tid + i * BLOCK;
-        if (idx < cnt) {
+        if (RDST_K4_VALID(i)) {
             const uint32_t v = kv[i] & 0xFFFFu, mine = kv[i] >> 16;
             const uint32_t wd = word_of(v);
             const uint32_t below = cnt4[wd] & ((1u << ((v & 7u) * 4u)) - 1u);
-            const uint32_t slot = nibble_sum(below, (uint32_t)prefix[wd] + mine);
+            const uint32_t slot = nibble_sum(below, (uint32_t)prefix[wd] + mine + mis);
             kv[i] = v | (slot << 16);
         }
+        RDST_K4_FENCE(i);
+    }
     }
     __syncthreads();  // every read of the tables is done: their space becomes the output staging
+    {
+    RDST_K4_PHASE();
+    RDST_K4_OPAQUE();
 #pragma unroll
     for (int i = 0; i < MAXR; ++i) {
-        const uint32_t idx = (uint32_t)tid + i * BLOCK;
-        if (idx < cnt) out16[kv[i] >> 16] = (uint16_t)kv[i];
+        if (RDST_K4_VALID(i)) out16[kv[i] >> 16] = (uint16_t)kv[i];
+    }
     }
     __syncthreads();
     __builtin_amdgcn_s_setprio(RDST_PRIO_SCATTER);
-    uint32_t* tdst = buf + start;
     const uint32_t top = bucket_prefix16(plan, bucket) << 16;
+    const uint32_t quads = (cnt + mis + 3u) >> 2;  // staged positions [mis, mis + cnt) in quads of four
+    constexpr int QR = (COUNT_TILE + 3 + 3) / 4 / BLOCK + 1;
+    const uint2* o2 = reinterpret_cast<const uint2*>(out16);
+    uint4* gq = reinterpret_cast<uint4*>(tdst - mis);  // 16-byte aligned (quad 0 may begin before the bucket: its first `mis` keys are not stored)
 #pragma unroll
-    for (int i = 0; i < MAXR; ++i) {
-        const uint32_t idx = (uint32_t)tid + i * BLOCK;
-        if (idx < cnt) {
-            const uint32_t m = top | (uint32_t)out16[idx];
-            tdst[idx] = MAPPED ? unmap_key<uint32_t>(m, neg, pos) : m;
+    for (int r = 0; r < QR; ++r) {
+        const uint32_t qi = (uint32_t)tid + (uint32_t)r * BLOCK;
+        if (qi < quads) {
+            const uint2 h = o2[qi];
+            uint4 k4;
+            k4.x = top | (h.x & 0xFFFFu); k4.y = top | (h.x >> 16); k4.z = top | (h.y & 0xFFFFu); k4.w = top | (h.y >> 16);
+            if constexpr (MAPPED) {
+                k4.x = unmap_key<uint32_t>(k4.x, neg, pos); k4.y = unmap_key<uint32_t>(k4.y, neg, pos);
+                k4.z = unmap_key<uint32_t>(k4.z, neg, pos); k4.w = unmap_key<uint32_t>(k4.w, neg, pos);
+            }
+            const uint32_t p0 = 4u * qi;  // staged position of the quad's first key; the bucket's keys are [mis, mis + cnt)
+            if (p0 >= mis && p0 + 3u < mis + cnt) {
+                gq[qi] = k4;
+            } else {  // the bucket's first and last quad
+                uint32_t* g = reinterpret_cast<uint32_t*>(gq + qi);
+                if (p0 + 0u >= mis && p0 + 0u < mis + cnt) g[0] = k4.x;
+                if (p0 + 1u >= mis && p0 + 1u < mis + cnt) g[1] = k4.y;
+                if (p0 + 2u >= mis && p0 + 2u < mis + cnt) g[2] = k4.z;
+                if (p0 + 3u >= mis && p0 + 3u < mis + cnt) g[3] = k4.w;
+            }
         }
     }
+}
+#undef RDST_K4_PHASE
+#undef RDST_K4_FENCE
+#undef RDST_K4_OPAQUE
+#undef RDST_K4_VALID
+
+template <int BLOCK, bool MAPPED, bool FROM16>
+__global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 8 : 6) void local_count_sort_kernel(
+    uint32_t* __restrict__ buf_keys, uint32_t* __restrict__ buf_tmp, const uint16_t* __restrict__ src16, const uint32_t* __restrict__ bstart,
+    const Plan* __restrict__ plan, uint32_t* __restrict__ err, uint32_t neg, uint32_t pos, uint32_t* __restrict__ list,
+    uint32_t* __restrict__ list_count, const uint32_t* __restrict__ slot_count /* ROUTE_ATOMIC: bucket b's halves lie in slot b (slot_cap
+    entries) of src16 and number slot_count[b]; NULL: they lie at their final place, bstart */, uint32_t slot_cap) {
+    if (!plan->local_sort) return;
+    if (plan->route != ROUTE_ATOMIC) slot_count = nullptr;  // the hybrid route's buckets lie at their final place (src16: position for position)
+    uint32_t* __restrict__ buf = plan->result_in_tmp ? buf_tmp : buf_keys;
+    const uint32_t bucket = blockIdx.x;
+    const uint32_t start = bstart[bucket], cnt = slot_count ? slot_count[bucket] : bstart[bucket + 1] - start;
+    const uint32_t soff = slot_count ? bucket * slot_cap : start;  // where the bucket's keys lie now
+    const int tid = threadIdx.x;
+    if (cnt <= 1) {
+        if constexpr (FROM16) {  // the key exists only as its low half: put it back together
+            if (cnt == 1 && tid == 0) {
+                const uint32_t m = (bucket_prefix16(plan, bucket) << 16) | (uint32_t)src16[soff];
+                buf[start] = MAPPED ? unmap_key<uint32_t>(m, neg, pos) : m;
+            }
+        }
+        return;
+    }
+    if (cnt >= GIANT_MIN && plan->giants) return;  // the giant kernels' (route_kernel listed it)
+    if (cnt > (uint32_t)COUNT_TILE || plan->low_dups) {  // more than this kernel stages, or (the sample says) low halves its 4-bit counters cannot count: handed on
+        if (tid == 0) list[atomicAdd(list_count, 1u)] = bucket;
+        return;
+    }
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const bool fast = cnt >= (uint32_t)COUNT_SAFE * BLOCK;  // block-uniform
+    if constexpr (FROM16 && BLOCK == 512) {
+        if (slot_count) {  // the atomic route: aligned slots
+            if (fast) count_sort_bucket<BLOCK, MAPPED, FROM16, true, true>(buf, src16, soff, start, cnt, bucket, plan, neg, pos, list, list_count, smem);
+            else count_sort_bucket<BLOCK, MAPPED, FROM16, false, true>(buf, src16, soff, start, cnt, bucket, plan, neg, pos, list, list_count, smem);
+            return;
+        }
+    }
+    if (fast) count_sort_bucket<BLOCK, MAPPED, FROM16, true, false>(buf, src16, soff, start, cnt, bucket, plan, neg, pos, list, list_count, smem);
+    else count_sort_bucket<BLOCK, MAPPED, FROM16, false, false>(buf, src16, soff, start, cnt, bucket, plan, neg, pos, list, list_count, smem);
 }
 
 // K4 for the buckets the kernel above hands on (4-byte keys): more keys than its tile, or a value seen 16 times.

@@ -484,8 +484,10 @@ def set_hybrid(enabled=True, min_len=0):
     keys (no 16-bit hand-off); 5 no presample; 6 8-byte keys with the one-block-per-CU K4; 8 the atomic route for 4-byte
     keys only (8-byte keys on the hybrid route); 9 the hybrid route without the expanding K4 (buckets up to one tile only);
     10 the default without the hybrid route as the atomic route's first fallback; 11 the default without the giant kernels
-    (4-byte keys: a bucket of 65 536 keys and more sends the sort down the LSD route)."""
-    _lib.check(_lib.load().rdst_hip_set_hybrid(int(enabled) if enabled in (2, 3, 5, 6, 7, 8, 9, 10, 11, 12) else int(bool(enabled)), int(min_len)))
+    (4-byte keys: a bucket of 65 536 keys and more sends the sort down the LSD route); 12 the default without the exact form
+    of the MSD passes; 14 the default without the sample's prediction of the LSD route; 15 the default with the second form
+    of the 8-byte K4 (local_wide2_sort_kernel)."""
+    _lib.check(_lib.load().rdst_hip_set_hybrid(int(enabled) if enabled in (2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 14, 15) else int(bool(enabled)), int(min_len)))
 
 
 def release_workspace(device=None) -> None:
