@@ -135,3 +135,33 @@ def test_overflow_raised_while_hundreds_of_tiles_run(gpu):
     finally:
         gpu.set_hybrid(True, 0)
     gpu.device_status()
+
+
+@pytest.mark.parametrize("name", ["uint64", "int64", "float64"])
+def test_wide_k4_settles_keys_that_agree_on_32_bits_below_the_bucket(gpu, name):
+    """8-byte K4 counts bits [32, 48) and orders the keys of one value by bits [16, 32); members that agree on those as well used to
+    send the whole bucket to the generic kernel.  Now they enter a list and are ordered by (low 16 bits, slot).  Keys built so that
+    every bucket (~500 keys) holds ~64 groups of ~8 with staged bits from 64 values and low bits from 4: dozens of such members
+    per bucket, among them keys that are equal in all 64 bits.  A second input makes the lists overflow (every group agrees on
+    its staged bits): those buckets must still come out right (generic kernel)."""
+    import torch
+    n = 32_000_000
+    g = torch.Generator(device="cuda").manual_seed(0x5D570330)
+    r = torch.randint(-(2**63), 2**63 - 1, (n,), dtype=torch.int64, device="cuda", generator=g)
+    top = r & (0xFFFF << 48) if False else (r >> 48) << 48            # random top 16 bits (sign included)
+    v16 = ((r >> 40) & 63) * 1009 % 65536                              # 64 values of bits [32, 48)
+    low = (r >> 8) & 3                                                 # 4 values of the low 16 bits
+    for mids, want_route in ((64, "atomic"), (1, "atomic")):
+        mid = ((r >> 20) & (mids - 1)) * 257
+        src = top | (v16 << 32) | (mid << 16) | low
+        keys = src.clone()
+        gpu.set_hybrid(True, 1)
+        try:
+            gpu.sort_device_tensor(keys.view(getattr(torch, name)))
+            assert gpu.last_route() == want_route
+        finally:
+            gpu.set_hybrid(True, 0)
+        kind = np.dtype(name).kind
+        want = torch.sort(_mapped(torch, src, kind)).values
+        assert bool(torch.equal(want, _mapped(torch, keys, kind))), (name, mids)
+    gpu.device_status()
