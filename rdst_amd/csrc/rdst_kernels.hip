@@ -3706,57 +3706,60 @@ __global__ __launch_bounds__(WIDE2_THREADS, 8) void local_wide2_sort_kernel(
 //    reads the even word as well, in the place phase and in the tie phase;
 //  * a key's index among equals and the size of its group are kept in two packed register pairs (4 bits x 16 keys each)
 //    instead of being re-read: the tie phase reads nothing but the staged bits of the group's members, and only for keys
-//    that have company (one in five on uniform keys).
-//  * FAST buckets (at least WIDE3_SAFE keys per thread: uniform 10^9-key sorts always, the mean is 7.5 sigma above) run their
-//    first WIDE3_SAFE rounds of every phase without the `idx < cnt` predicate; a thread's valid keys are its first `nvalid`,
-//    one register for every predicate of every phase (see count_sort_bucket for why each phase takes an opaque copy);
-//  * a group's staged bits are read with ONE (2-byte aligned) 8-byte LDS read — groups of up to four, 99.99 % of them; a larger
-//    group reads on in a loop;
-//  * two members of a group that agree on bits [16, 32) as well are no longer the end of the bucket (one bucket in seventy: 0.28
-//    of K4's 4.6 ms went to the generic kernel for them): such keys enter a small list (group and staged bits | low 16 bits
-//    and slot) in the prefix table — dead by then —, and each of them adds the entries of its own group and bits that go
-//    before it in (low bits, slot) order to its place.  Only a list of more than WIDE3_AMB_MAX entries (heavily repeated
-//    keys) still sends the bucket on.
+//    that have company (one in five on uniform keys);
+//  * two members of a group that agree on bits [16, 32) as well are settled by a small list instead of sending the bucket to the
+//    generic kernel (below).
+// (A fourth form — predicate-free rounds for full buckets as in count_sort_bucket, one 8-byte LDS read per tie group — was
+// correct and, for unsigned keys, 40 % SLOWER: at the 64 registers two blocks per CU allow it spilled a dozen values per thread
+// per phase, 100 KB of scratch traffic per 244-KB bucket.  Signed and float keys, whose map keeps fewer values live, ran as
+// fast as this form, not faster.)
 constexpr int WIDE3_THREADS = 1024;
+constexpr uint32_t WIDE3_AMB_MAX = 256;  // entries of 8 bytes in the (16-KiB) prefix table
 constexpr size_t wide3_lds_bytes() { return 32768 + 16384 + 2 * (size_t)local_tile(8); }  // 81 920 = 160 KiB / 2
 static_assert(wide3_lds_bytes() * 2 <= 160 * 1024, "two blocks per CU");
-constexpr int WIDE3_SAFE = 14;           // rounds (keys per thread) that need no predicate in a FAST bucket
-constexpr uint32_t WIDE3_AMB_MAX = 256;  // entries of 8 bytes in the (16-KiB) prefix table
 
-template <bool MAPPED, bool FAST>
-__device__ __forceinline__ void wide3_bucket(uint64_t* __restrict__ buf, const uint64_t* __restrict__ tsrc, uint32_t start, uint32_t cnt, uint32_t bucket,
-                                             const Plan* __restrict__ plan, uint64_t neg, uint64_t pos, uint32_t* __restrict__ list,
-                                             uint32_t* __restrict__ list_count, unsigned char* smem) {
+template <bool MAPPED>
+__global__ __launch_bounds__(WIDE3_THREADS, 8) void local_wide3_sort_kernel(
+    uint64_t* __restrict__ buf_keys, uint64_t* __restrict__ buf_tmp, const uint32_t* __restrict__ bstart, const Plan* __restrict__ plan,
+    uint32_t* __restrict__ err, uint64_t neg, uint64_t pos, uint32_t* __restrict__ list, uint32_t* __restrict__ list_count,
+    const uint64_t* __restrict__ src_slots /* ROUTE_ATOMIC: bucket b's keys lie in slot b (slot_cap keys) and number slot_count[b]; NULL: in place */,
+    const uint32_t* __restrict__ slot_count, uint32_t slot_cap) {
     constexpr int TILE = local_tile(8);
     constexpr int BLOCK = WIDE3_THREADS, MAXR = TILE / BLOCK, WPT = H16_BINS / BLOCK / 8, LOG_VPT = 6;
     constexpr int HALF = TILE / 2;
     static_assert(MAXR == 16, "two 64-bit registers of 4-bit fields, one field per key");
     static_assert((size_t)HALF * 8 <= 32768 + 16384 + 2 * (size_t)TILE - 4, "output staging fits below the flag word");
-    static_assert(WIDE3_SAFE < MAXR && (size_t)WIDE3_AMB_MAX * 8 <= 16384, "list fits the prefix table");
+    if (!plan->local_sort) return;
+    if (plan->route != ROUTE_ATOMIC) src_slots = nullptr;  // the hybrid route's buckets lie at their final place
+    uint64_t* __restrict__ buf = plan->result_in_tmp ? buf_tmp : buf_keys;
+    const uint32_t bucket = blockIdx.x;
+    const uint32_t start = bstart[bucket], cnt = src_slots ? slot_count[bucket] : bstart[bucket + 1] - start;
+    if (cnt == 0 || (cnt == 1 && !src_slots)) return;  // (a single key in a slot still has to be moved to its place)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (cnt > (uint32_t)TILE) {
+        if (tid == 0) atomicOr(err, ERR_LOCAL_OVERFLOW);
+        return;
+    }
+    if (cnt > (uint32_t)TILE - 2u) {  // the last two entries of the staged bits are the flag word: such a bucket goes to the generic kernel
+        if (tid == 0) list[atomicAdd(list_count, 1u)] = bucket;
+        return;
+    }
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* cnt4 = reinterpret_cast<uint32_t*>(smem);                              // [WPT][BLOCK] eight 4-bit counters per word
     uint16_t* prefix = reinterpret_cast<uint16_t*>(smem + 32768);                    // [WPT][BLOCK] keys below the word
-    uint2* amb = reinterpret_cast<uint2*>(smem + 32768);                             // [WIDE3_AMB_MAX] keys with an equal in bits [16, 48) (tie phase: the prefixes are dead)
     uint16_t* mid16 = reinterpret_cast<uint16_t*>(smem + 32768 + 16384);             // [TILE] bits [16, 32) of the keys at their slots
     uint32_t* s_wsum = reinterpret_cast<uint32_t*>(smem + 32768 + 16384);            // [16] wave sums (scan phase: the staged bits are not there yet)
     uint32_t* s_flag = reinterpret_cast<uint32_t*>(smem + 32768 + 16384 + 2 * TILE - 4);  // count phase: overflow; tie phase: length of the list (never a slot: cnt <= TILE - 2)
+    uint2* amb = reinterpret_cast<uint2*>(smem + 32768);                             // [WIDE3_AMB_MAX] keys with an equal in bits [16, 48) (tie phase: the prefixes are dead)
     uint64_t* out64 = reinterpret_cast<uint64_t*>(smem);                             // [HALF] output staging (the tables are dead by then)
-    const uint32_t nvalid = cnt > (uint32_t)tid ? (cnt - (uint32_t)tid + BLOCK - 1u) / BLOCK : 0u;  // key i of this thread is element tid + i * BLOCK
-#define RDST_W3_PHASE() uint32_t nv_ = nvalid; asm volatile("" : "+v"(nv_))
-#define RDST_W3_VALID(i) ((FAST && (i) < WIDE3_SAFE) || (uint32_t)(i) < nv_)
-    // (a group of rounds is pinned where it is computed: without predicates a phase is one basic block, and the compiler, left
-    // alone, issues every round's LDS reads first and spills their results)
-#define RDST_W3_PIN(i) do { if (((i) & 3) == 3) { _Pragma("unroll") for (int f_ = (i) - 3; f_ <= (i); ++f_) asm volatile("" : "+v"(mk[f_])); } } while (0)
     RDST_TL_BEGIN(1);
     __builtin_amdgcn_s_setprio(RDST_PRIO_LOAD);
+    const uint64_t* tsrc = src_slots ? src_slots + (uint64_t)bucket * slot_cap : buf + start;
     uint64_t mk[MAXR];
-    {
-        RDST_W3_PHASE();
 #pragma unroll
-        for (int i = 0; i < MAXR; ++i) {
-            const uint32_t idx = (uint32_t)tid + i * BLOCK;
-            mk[i] = tsrc[RDST_W3_VALID(i) ? idx : cnt - 1];
-        }
+    for (int i = 0; i < MAXR; ++i) {
+        const uint32_t idx = (uint32_t)tid + i * BLOCK;
+        mk[i] = tsrc[idx < cnt ? idx : cnt - 1];
     }
 #pragma unroll
     for (int k = 0; k < WPT; ++k) cnt4[k * BLOCK + tid] = 0;
@@ -3769,20 +3772,17 @@ __device__ __forceinline__ void wide3_bucket(uint64_t* __restrict__ buf, const u
     constexpr uint64_t LOW48 = (1ull << 48) - 1;  // a key's slot rides in its top 16 bits (the bucket index, restored at the end)
     uint64_t mine_pack = 0, group_pack = 0;       // per key: index among the keys of its value, size of that group
     bool flag = false;
-    {
-        RDST_W3_PHASE();
 #pragma unroll
-        for (int i = 0; i < MAXR; ++i) {
-            if (RDST_W3_VALID(i)) {
-                if constexpr (MAPPED) mk[i] = map_key<uint64_t>(mk[i], neg, pos);
-                const uint32_t v = (uint32_t)(mk[i] >> 32) & 0xFFFFu;
-                const uint32_t sh = (v & 7u) * 4u;
-                const uint32_t old = atomicAdd(&cnt4[word_of(v)], 1u << sh);
-                const uint32_t mine = (old >> sh) & 15u;
-                flag |= mine == 15u;
-                mine_pack |= (uint64_t)mine << (4 * i);
-            }
-            if ((i & 3) == 3) asm volatile("" : "+v"(mine_pack));
+    for (int i = 0; i < MAXR; ++i) {
+        const uint32_t idx = (uint32_t)tid + i * BLOCK;
+        if (idx < cnt) {
+            if constexpr (MAPPED) mk[i] = map_key<uint64_t>(mk[i], neg, pos);
+            const uint32_t v = (uint32_t)(mk[i] >> 32) & 0xFFFFu;
+            const uint32_t sh = (v & 7u) * 4u;
+            const uint32_t old = atomicAdd(&cnt4[word_of(v)], 1u << sh);
+            const uint32_t mine = (old >> sh) & 15u;
+            flag |= mine == 15u;
+            mine_pack |= (uint64_t)mine << (4 * i);
         }
     }
     if (flag) *s_flag = 1;
@@ -3817,30 +3817,27 @@ __device__ __forceinline__ void wide3_bucket(uint64_t* __restrict__ buf, const u
     }
     __syncthreads();  // (also: every read of the wave sums is done before the staged bits overwrite them)
     RDST_STAMP(4);
-    {
-        RDST_W3_PHASE();
 #pragma unroll
-        for (int i = 0; i < MAXR; ++i) {
-            if (RDST_W3_VALID(i)) {
-                const uint32_t v = (uint32_t)(mk[i] >> 32) & 0xFFFFu;
-                const uint32_t wd = word_of(v), sh = (v & 7u) * 4u;
-                const uint32_t w = cnt4[wd];
-                const uint32_t first = nibble_sum(w & ((1u << sh) - 1u), (uint32_t)prefix[wd]);
-                const uint32_t slot = first + ((uint32_t)(mine_pack >> (4 * i)) & 15u);
-                group_pack |= (uint64_t)((w >> sh) & 15u) << (4 * i);
-                mid16[slot] = (uint16_t)((uint32_t)mk[i] >> 16);
-                mk[i] = (mk[i] & LOW48) | ((uint64_t)slot << 48);
-            }
-            RDST_W3_PIN(i);
-            if ((i & 3) == 3) asm volatile("" : "+v"(group_pack));
+    for (int i = 0; i < MAXR; ++i) {
+        const uint32_t idx = (uint32_t)tid + i * BLOCK;
+        if (idx < cnt) {
+            const uint32_t v = (uint32_t)(mk[i] >> 32) & 0xFFFFu;
+            const uint32_t wd = word_of(v), sh = (v & 7u) * 4u;
+            const uint32_t w = cnt4[wd];
+            const uint32_t first = nibble_sum(w & ((1u << sh) - 1u), (uint32_t)prefix[wd]);
+            const uint32_t slot = first + ((uint32_t)(mine_pack >> (4 * i)) & 15u);
+            group_pack |= (uint64_t)((w >> sh) & 15u) << (4 * i);
+            mid16[slot] = (uint16_t)((uint32_t)mk[i] >> 16);
+            mk[i] = (mk[i] & LOW48) | ((uint64_t)slot << 48);
         }
     }
     RDST_STAMP(5);
     __syncthreads();
     // ties: my place inside my group = first slot + members with smaller bits [16, 32).  A key with a member that agrees on those
-    // bits as well keeps its slot for now, remembers that count in its group field (free from here on), and enters the list
-    // (whose length is counted in the flag word, which the count phase left at 0).
-    uint32_t amb_mask = 0;
+    // bits as well (one bucket in seventy holds such a pair on uniform keys: 0.28 of K4's 4.6 ms went to the generic kernel for
+    // them) keeps its slot for now, clears its group field — valid keys have at least 1 there — and enters a list in the prefix
+    // table, dead by now: (group's first slot, staged bits | low 16 bits, slot).  The list's length is counted in the flag word,
+    // which the count phase left at 0.
 #pragma unroll
     for (int i = 0; i < MAXR; ++i) {
         const uint32_t group = (uint32_t)(group_pack >> (4 * i)) & 15u;  // (0 for the slots past cnt)
@@ -3848,24 +3845,15 @@ __device__ __forceinline__ void wide3_bucket(uint64_t* __restrict__ buf, const u
             const uint32_t slot = (uint32_t)(mk[i] >> 48);
             const uint32_t first = slot - ((uint32_t)(mine_pack >> (4 * i)) & 15u);
             const uint32_t mid = ((uint32_t)mk[i] >> 16) & 0xFFFFu;
-            typedef uint64_t u64_a2 __attribute__((aligned(2)));
-            const uint64_t four = *reinterpret_cast<const u64_a2*>(mid16 + first);  // members 0..3 (first + 3 < TILE: the flag word's halves at worst)
-            uint32_t rank = 0, same = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t other = (uint32_t)(four >> (16 * j)) & 0xFFFFu;
-                const bool in = (uint32_t)j < group;
-                rank += (in && other < mid) ? 1u : 0u;
-                same += (in && other == mid) ? 1u : 0u;
-            }
-            for (uint32_t j = 4; j < group; ++j) {  // (a group of five and more: one key in 10^5 on uniform keys)
+            uint32_t rank = 0;
+            bool twin = false;
+            for (uint32_t j = 0; j < group; ++j) {
                 const uint32_t other = mid16[first + j];
                 rank += other < mid ? 1u : 0u;
-                same += other == mid ? 1u : 0u;
+                twin |= other == mid && first + j != slot;
             }
-            if (same >= 2u) {  // (the count includes me)
-                amb_mask |= 1u << i;
-                group_pack = (group_pack & ~(15ull << (4 * i))) | ((uint64_t)rank << (4 * i));
+            if (twin) {
+                group_pack &= ~(15ull << (4 * i));
                 const uint32_t e = atomicAdd(s_flag, 1u);
                 if (e < WIDE3_AMB_MAX) amb[e] = make_uint2((first << 16) | mid, (((uint32_t)mk[i] & 0xFFFFu) << 16) | slot);
             } else {
@@ -3876,25 +3864,35 @@ __device__ __forceinline__ void wide3_bucket(uint64_t* __restrict__ buf, const u
     RDST_STAMP(6);
     __syncthreads();  // every look at the staged bits is done, the list is complete
     const uint32_t namb = *s_flag;
-    if (namb > WIDE3_AMB_MAX) {  // block-uniform: heavily repeated keys
+    if (namb > WIDE3_AMB_MAX) {  // block-uniform: heavily repeated keys go to the generic kernel after all
         if (tid == 0) list[atomicAdd(list_count, 1u)] = bucket;
         return;
     }
-    if (namb) {  // block-uniform; one bucket in seventy on uniform keys, a pair of entries then
-#pragma unroll
+    if (namb) {  // block-uniform and rare (a pair of entries in one bucket of seventy): nothing in here has to be fast
+#pragma unroll 1
         for (int i = 0; i < MAXR; ++i) {
-            if ((amb_mask >> i) & 1u) {
-                const uint32_t slot = (uint32_t)(mk[i] >> 48);
-                const uint32_t first = slot - ((uint32_t)(mine_pack >> (4 * i)) & 15u);
-                const uint32_t me_x = (first << 16) | (((uint32_t)mk[i] >> 16) & 0xFFFFu);
-                const uint32_t me_y = (((uint32_t)mk[i] & 0xFFFFu) << 16) | slot;
-                uint32_t before = 0;  // entries of my group and staged bits that go before me: smaller low bits, or the same and an earlier slot
-                for (uint32_t e = 0; e < namb; ++e) {
-                    const uint2 x = amb[e];
-                    before += (x.x == me_x && x.y < me_y) ? 1u : 0u;
-                }
-                mk[i] = (mk[i] & LOW48) | ((uint64_t)(first + ((uint32_t)(group_pack >> (4 * i)) & 15u) + before) << 48);
+            // a loop, not sixteen copies; the keys of the list are found by their cleared group field, and register i of the key
+            // array is reached through selects
+            if ((uint32_t)tid + (uint32_t)i * BLOCK >= cnt || ((uint32_t)(group_pack >> (4 * i)) & 15u) != 0u) continue;
+            uint64_t key = 0;
+#pragma unroll
+            for (int q = 0; q < MAXR; ++q) key = q == i ? mk[q] : key;
+            const uint32_t slot = (uint32_t)(key >> 48);
+            const uint32_t v = (uint32_t)(key >> 32) & 0xFFFFu;
+            const uint32_t group = (cnt4[word_of(v)] >> ((v & 7u) * 4u)) & 15u;  // (the counters are intact until the output is staged)
+            const uint32_t first = slot - ((uint32_t)(mine_pack >> (4 * i)) & 15u);
+            const uint32_t mid = ((uint32_t)key >> 16) & 0xFFFFu;
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < group; ++j) rank += mid16[first + j] < mid ? 1u : 0u;
+            const uint32_t me_x = (first << 16) | mid, me_y = (((uint32_t)key & 0xFFFFu) << 16) | slot;
+            uint32_t before = 0;  // entries of my group and staged bits that go before me: smaller low bits, or the same and an earlier slot
+            for (uint32_t e = 0; e < namb; ++e) {
+                const uint2 x = amb[e];
+                before += (x.x == me_x && x.y < me_y) ? 1u : 0u;
             }
+            key = (key & LOW48) | ((uint64_t)(first + rank + before) << 48);
+#pragma unroll
+            for (int q = 0; q < MAXR; ++q) mk[q] = q == i ? key : mk[q];
         }
         __syncthreads();  // the list lies where the output staging begins
     }
@@ -3904,13 +3902,11 @@ __device__ __forceinline__ void wide3_bucket(uint64_t* __restrict__ buf, const u
     for (int h = 0; h < 2; ++h) {
         if (h == 1 && cnt <= (uint32_t)HALF) break;  // block-uniform
         __builtin_amdgcn_s_setprio(0);
-        {
-            RDST_W3_PHASE();
 #pragma unroll
-            for (int i = 0; i < MAXR; ++i) {
-                const uint32_t rel = (uint32_t)(mk[i] >> 48) - (uint32_t)(h * HALF);
-                if (RDST_W3_VALID(i) && rel < (uint32_t)HALF) out64[rel] = (mk[i] & LOW48) | top;
-            }
+        for (int i = 0; i < MAXR; ++i) {
+            const uint32_t idx = (uint32_t)tid + i * BLOCK;
+            const uint32_t rel = (uint32_t)(mk[i] >> 48) - (uint32_t)(h * HALF);
+            if (idx < cnt && rel < (uint32_t)HALF) out64[rel] = (mk[i] & LOW48) | top;
         }
         __syncthreads();
         if (h == 0) RDST_STAMP(7);
@@ -3925,37 +3921,6 @@ __device__ __forceinline__ void wide3_bucket(uint64_t* __restrict__ buf, const u
     }
     RDST_STAMP(9);
     RDST_TL_END(bucket);
-#undef RDST_W3_PHASE
-#undef RDST_W3_VALID
-#undef RDST_W3_PIN
-}
-
-template <bool MAPPED>
-__global__ __launch_bounds__(WIDE3_THREADS, 8) void local_wide3_sort_kernel(
-    uint64_t* __restrict__ buf_keys, uint64_t* __restrict__ buf_tmp, const uint32_t* __restrict__ bstart, const Plan* __restrict__ plan,
-    uint32_t* __restrict__ err, uint64_t neg, uint64_t pos, uint32_t* __restrict__ list, uint32_t* __restrict__ list_count,
-    const uint64_t* __restrict__ src_slots /* ROUTE_ATOMIC: bucket b's keys lie in slot b (slot_cap keys) and number slot_count[b]; NULL: in place */,
-    const uint32_t* __restrict__ slot_count, uint32_t slot_cap) {
-    constexpr int TILE = local_tile(8);
-    if (!plan->local_sort) return;
-    if (plan->route != ROUTE_ATOMIC) src_slots = nullptr;  // the hybrid route's buckets lie at their final place
-    uint64_t* __restrict__ buf = plan->result_in_tmp ? buf_tmp : buf_keys;
-    const uint32_t bucket = blockIdx.x;
-    const uint32_t start = bstart[bucket], cnt = src_slots ? slot_count[bucket] : bstart[bucket + 1] - start;
-    if (cnt == 0 || (cnt == 1 && !src_slots)) return;  // (a single key in a slot still has to be moved to its place)
-    const int tid = threadIdx.x;
-    if (cnt > (uint32_t)TILE) {
-        if (tid == 0) atomicOr(err, ERR_LOCAL_OVERFLOW);
-        return;
-    }
-    if (cnt > (uint32_t)TILE - 2u) {  // the last two entries of the staged bits are the flag word: such a bucket goes to the generic kernel
-        if (tid == 0) list[atomicAdd(list_count, 1u)] = bucket;
-        return;
-    }
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint64_t* tsrc = src_slots ? src_slots + (uint64_t)bucket * slot_cap : buf + start;
-    if (cnt >= (uint32_t)WIDE3_SAFE * WIDE3_THREADS) wide3_bucket<MAPPED, true>(buf, tsrc, start, cnt, bucket, plan, neg, pos, list, list_count, smem);
-    else wide3_bucket<MAPPED, false>(buf, tsrc, start, cnt, bucket, plan, neg, pos, list, list_count, smem);
 }
 
 // result sits in tmp after an odd number of executed passes: copy back
