@@ -2657,7 +2657,7 @@ __device__ __forceinline__ void count_sort_bucket(uint32_t* __restrict__ buf, co
     if (tid == 0) s_wsum[16] = 0;
     __syncthreads();
     __builtin_amdgcn_s_setprio(0);
-    auto word_of = [](uint32_t v) -> uint32_t { return ((v >> 3) & (uint32_t)(WPT - 1)) * BLOCK + (v >> LOG_VPT); };
+    auto word_of = [](uint32_t v) -> uint32_t { return v >> 3; };  // (linear: consecutive values lie on consecutive banks — dense ids put 128 of them on ONE bank in the thread-major table —, and the address is two instructions instead of five; the scan pays with a rotated read order)
     bool over = false;
     {
     RDST_K4_PHASE();
@@ -2704,13 +2704,22 @@ __device__ __forceinline__ void count_sort_bucket(uint32_t* __restrict__ buf, co
         return;
     }
     {
-        uint32_t pre[WPT];
-        uint32_t run = 0;
+        // thread t owns words [WPT t, WPT t + WPT) and reads them in a rotated order — word (k + r) mod WPT in step k, r = t / (64 / WPT)
+        // — so that the 64 lanes of a step sit on 64 different banks; the prefixes are put right afterwards: the words from r up
+        // arrive first (before them lie the words below r: total - the sum through the last word), the words below r after those
+        constexpr int ROT_SHIFT = WPT == 16 ? 2 : 3;
+        static_assert(WPT == 16 || WPT == 8, "64 banks / WPT lanes per rotation");
+        const uint32_t r = ((uint32_t)tid >> ROT_SHIFT) & (uint32_t)(WPT - 1);
+        uint32_t arr[WPT];  // keys in the words that arrived before step k
+        uint32_t run = 0, through_last = 0;
 #pragma unroll
         for (int k = 0; k < WPT; ++k) {
-            pre[k] = run;
-            run = nibble_sum(cnt4[k * BLOCK + tid], run);
+            const uint32_t j = ((uint32_t)k + r) & (uint32_t)(WPT - 1);
+            arr[k] = run;
+            run = nibble_sum(cnt4[WPT * tid + j], run);
+            through_last = j == (uint32_t)(WPT - 1) ? run : through_last;
         }
+        const uint32_t below_r = run - through_last;  // keys in my words 0 .. r - 1
         uint32_t incl = run;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -2724,7 +2733,11 @@ __device__ __forceinline__ void count_sort_bucket(uint32_t* __restrict__ buf, co
         for (int x = 0; x < BLOCK / 64; ++x)
             if (x < wave) base += s_wsum[x];
 #pragma unroll
-        for (int k = 0; k < WPT; ++k) prefix[k * BLOCK + tid] = (uint16_t)(base + pre[k]);
+        for (int k = 0; k < WPT; ++k) {
+            const uint32_t j = ((uint32_t)k + r) & (uint32_t)(WPT - 1);
+            const uint32_t before = (uint32_t)k + r < (uint32_t)WPT ? below_r + arr[k] : arr[k] - through_last;
+            prefix[WPT * tid + j] = (uint16_t)(base + before);
+        }
     }
     __syncthreads();
     // the staging is shifted by the destination's misalignment (in keys, 0..3): LDS quad q then is the 16-byte aligned global quad q
@@ -3768,7 +3781,7 @@ __global__ __launch_bounds__(WIDE3_THREADS, 8) void local_wide3_sort_kernel(
     __syncthreads();
     RDST_STAMP(2);
     __builtin_amdgcn_s_setprio(0);
-    auto word_of = [](uint32_t v) -> uint32_t { return ((v >> 3) & (uint32_t)(WPT - 1)) * BLOCK + (v >> LOG_VPT); };
+    auto word_of = [](uint32_t v) -> uint32_t { return v >> 3; };  // (linear: consecutive values lie on consecutive banks — dense ids put 128 of them on ONE bank in the thread-major table —, and the address is two instructions instead of five; the scan pays with a rotated read order)
     constexpr uint64_t LOW48 = (1ull << 48) - 1;  // a key's slot rides in its top 16 bits (the bucket index, restored at the end)
     uint64_t mine_pack = 0, group_pack = 0;       // per key: index among the keys of its value, size of that group
     bool flag = false;
@@ -3793,13 +3806,22 @@ __global__ __launch_bounds__(WIDE3_THREADS, 8) void local_wide3_sort_kernel(
         return;
     }
     {
-        uint32_t pre[WPT];
-        uint32_t run = 0;
+        // thread t owns words [WPT t, WPT t + WPT) and reads them in a rotated order — word (k + r) mod WPT in step k, r = t / (64 / WPT)
+        // — so that the 64 lanes of a step sit on 64 different banks; the prefixes are put right afterwards: the words from r up
+        // arrive first (before them lie the words below r: total - the sum through the last word), the words below r after those
+        constexpr int ROT_SHIFT = WPT == 16 ? 2 : 3;
+        static_assert(WPT == 16 || WPT == 8, "64 banks / WPT lanes per rotation");
+        const uint32_t r = ((uint32_t)tid >> ROT_SHIFT) & (uint32_t)(WPT - 1);
+        uint32_t arr[WPT];  // keys in the words that arrived before step k
+        uint32_t run = 0, through_last = 0;
 #pragma unroll
         for (int k = 0; k < WPT; ++k) {
-            pre[k] = run;
-            run = nibble_sum(cnt4[k * BLOCK + tid], run);
+            const uint32_t j = ((uint32_t)k + r) & (uint32_t)(WPT - 1);
+            arr[k] = run;
+            run = nibble_sum(cnt4[WPT * tid + j], run);
+            through_last = j == (uint32_t)(WPT - 1) ? run : through_last;
         }
+        const uint32_t below_r = run - through_last;  // keys in my words 0 .. r - 1
         uint32_t incl = run;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -3813,7 +3835,11 @@ __global__ __launch_bounds__(WIDE3_THREADS, 8) void local_wide3_sort_kernel(
         for (int x = 0; x < BLOCK / 64; ++x)
             if (x < wave) base += s_wsum[x];
 #pragma unroll
-        for (int k = 0; k < WPT; ++k) prefix[k * BLOCK + tid] = (uint16_t)(base + pre[k]);
+        for (int k = 0; k < WPT; ++k) {
+            const uint32_t j = ((uint32_t)k + r) & (uint32_t)(WPT - 1);
+            const uint32_t before = (uint32_t)k + r < (uint32_t)WPT ? below_r + arr[k] : arr[k] - through_last;
+            prefix[WPT * tid + j] = (uint16_t)(base + before);
+        }
     }
     __syncthreads();  // (also: every read of the wave sums is done before the staged bits overwrite them)
     RDST_STAMP(4);
