@@ -118,7 +118,7 @@ def _splits(table, owner, rank, world):
     return torch.cat([send, recv, share.max()[None], table.sum()[None]])
 
 
-def sharded_sort(local_keys, group=None, engine=None, return_info: bool = False):
+def sharded_sort(local_keys, group=None, engine=None, return_info: bool = False, force_collectives: bool = False):
     """Globally sort the concatenation of every rank's `local_keys`; returns this rank's slice
     (a new tensor whose length is the number of keys that fall into this rank's range).
     Collective: every rank of `group` must call it."""
@@ -129,7 +129,7 @@ def sharded_sort(local_keys, group=None, engine=None, return_info: bool = False)
         engine = HipEngine()
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    if world == 1:
+    if world == 1 and not force_collectives:  # (force_collectives: a one-rank group still runs every collective — the RCCL smoke test)
         out = local_keys.clone()
         engine.sort(out)
         return (out, {"owner": [0] * 256, "recv": [out.numel()], "send": [out.numel()], "split_bits": 8}) if return_info else out

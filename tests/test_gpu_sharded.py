@@ -101,3 +101,39 @@ def test_split_entries_match_the_oracle(gpu, oracle):
             assert same_bits(to_host(srt, dtype), a[order]), (dtype, n)
             assert np.array_equal(c16.cpu().numpy(), np.bincount(prefix, minlength=65536)), (dtype, n)
     gpu.device_status()
+
+
+def _nccl_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    try:
+        import rdst_amd
+        from helpers import random_bits, reference_sorted, same_bits, to_device, to_host
+        from rdst_amd.sharded import sharded_sort
+        for dtype_name in ("uint64", "uint32", "float32", "int64"):
+            a = random_bits(2_000_003, dtype_name, seed=0x5D570040).copy()
+            out, info = sharded_sort(to_device(a), return_info=True, force_collectives=True)
+            rdst_amd.device_status()
+            assert info["recv"] == [a.size] and info["send"] == [a.size], info
+            assert same_bits(to_host(out, dtype_name), reference_sorted(a)), dtype_name
+        open(os.path.join(out_dir, "ok"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_collectives_over_rccl_with_one_rank(tmp_path, gpu):
+    """The box has one GPU and RCCL refuses two ranks on one device, so the all-gather and the all-to-all of the sharded route had
+    never executed on the `nccl` backend.  A one-rank RCCL group runs them for real — device tensors, the int views,
+    the split-size plumbing — and the result must be the plain sort of the shard.  (A single rank never owns more than its
+    share, so the 16-bit split's table does not travel here.)"""
+    import torch.multiprocessing as mp
+    port = 29500 + (os.getpid() + 77) % 2000
+    mp.spawn(_nccl_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    assert (tmp_path / "ok").exists()
