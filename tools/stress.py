@@ -52,7 +52,11 @@ def gen(n, it, kind):
 
 
 t0, runs, fails, total_keys, big = time.time(), 0, 0, 0, 0
+last_note = t0
 while time.time() - t0 < budget:
+    if time.time() - last_note > 30:   # (a long run must show signs of life)
+        last_note = time.time()
+        print(f"  ... {runs} sorts, {total_keys:.3e} keys, {fails} failures after {last_note - t0:.0f} s", flush=True)
     name, it = types[int(torch.randint(0, len(types), (1,)))]
     e = float(sys.argv[3]) + float(torch.rand(1)) * float(sys.argv[4]) if len(sys.argv) > 4 else 3.0 + float(torch.rand(1)) * 4.6
     n = max(1, int(10 ** e))
@@ -60,7 +64,7 @@ while time.time() - t0 < budget:
     if os.environ.get("RDST_STRESS_TYPES") and name not in os.environ["RDST_STRESS_TYPES"].split(","): continue
     kind = int(torch.randint(0, 14, (1,)))
     # route knobs: the default, the routes considered at every length, and the A/B modes
-    mode = [1, 1, 7, 8, 10, 11, 3, 9][int(torch.randint(0, 8, (1,)))]
+    mode = [1, 1, 1, 7, 8, 10, 11, 3, 9, 14, 15, 12][int(torch.randint(0, 12, (1,)))]
     rdst_amd.set_hybrid(mode, 1 if int(torch.randint(0, 3, (1,))) else 0)
     total_keys += n; big += n > 1_000_000
     split, fast = bool(torch.randint(0, 2, (1,))), int(torch.randint(0, 3, (1,)))

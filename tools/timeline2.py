@@ -12,10 +12,14 @@ import rdst_amd
 lib = _lib.load()
 name, which = sys.argv[1], int(sys.argv[2])
 n = int(float(sys.argv[3])) if len(sys.argv) > 3 else 10**9
-it = torch.int32 if name == "uint32" else torch.int64
 g = torch.Generator(device="cuda").manual_seed(1)
-info = torch.iinfo(it)
-src = torch.randint(info.min, info.max, (n,), dtype=it, device="cuda", generator=g)
+if name == "float32n":   # a float column: normal(0, 1), sorted as f32 (the hybrid route's exact MSD passes)
+    name, it = "float32", torch.int32
+    src = torch.randn(n, dtype=torch.float32, device="cuda", generator=g).view(torch.int32)
+else:
+    it = torch.int32 if name == "uint32" else torch.int64
+    info = torch.iinfo(it)
+    src = torch.randint(info.min, info.max, (n,), dtype=it, device="cuda", generator=g)
 keys, tmp = src.clone(), torch.empty_like(src)
 view, tview = keys.view(getattr(torch, name)), tmp.view(getattr(torch, name))
 rdst_amd.sort_device_tensor(view, tview)
