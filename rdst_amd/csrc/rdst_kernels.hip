@@ -1997,25 +1997,35 @@ __global__ __launch_bounds__(NWAVES * 64, RDST_MSD_MINWAVES) void msd_scatter_ke
     uint32_t uniform_rounds = 0;
     uint32_t run_index[(KPT + 1) / 2];
     bool careful, fast, heavy = false;
-    uint32_t hd3[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};  // wave-uniform
+    constexpr int NHEAVY = 5;
+    uint32_t hd3[NHEAVY] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};  // wave-uniform
     {
         const uint32_t d0 = digit_of(mk[0], shift);
         const uint32_t dn = (uint32_t)__builtin_amdgcn_mov_dpp((int)d0, 0x138, 0xf, 0xf, false);
         careful = __builtin_popcountll(__builtin_amdgcn_ballot_w64(d0 == dn) & ~1ull) >= 8;
-        // up to three heavy digits (a float column's sign-and-exponent byte: 50 % / 37 % / 9 % of the keys on three values;
-        // K3's step 3 has the one-digit form): their lanes rank by one ballot each, the others by the returning add.  The
-        // candidates are the digits of three probed lanes; a candidate that less than an eighth of the round holds is dropped.
+        // up to five heavy digits (a float column's sign-and-exponent byte: uniform [0, 1) puts 50 % / 37 % / 9 % of the keys on
+        // three values, normal(0, 1) 24 / 24 / 19 / 19 % on four; K3's step 3 has the one-digit form): their lanes rank by one
+        // ballot each, the others by the returning add.  The candidates are the digits of five probed lanes; one that less
+        // than an eighth of the round holds, or that an earlier probe found, is dropped.  (Three candidates, round 2, left a
+        // normal column's fourth digit to the test below half of the time: one wave in four took the bit-by-bit path — 37
+        // instructions per key — and the other eleven of its block waited at two barriers: 16.8 us per tile against 11.3.)
         if (careful && full) {
+            bool any = false;
 #pragma unroll
-            for (int probe = 0; probe < 3; ++probe) {
-                const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)d0, probe * 21);
+            for (int probe = 0; probe < NHEAVY; ++probe) {
+                const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)d0, probe * 13);
                 const uint32_t k = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(d0 == c));
-                hd3[probe] = k >= 8 ? c : 0xFFFFFFFFu;  // (no digit is 0xFFFFFFFF: a dropped candidate matches nothing)
+                bool dup = false;
+#pragma unroll
+                for (int e = 0; e < probe; ++e) dup |= hd3[e] == c;
+                hd3[probe] = (k >= 8 && !dup) ? c : 0xFFFFFFFFu;  // (no digit is 0xFFFFFFFF: a dropped candidate matches nothing)
+                any |= hd3[probe] != 0xFFFFFFFFu;
             }
-            if (hd3[1] == hd3[0]) hd3[1] = 0xFFFFFFFFu;
-            if (hd3[2] == hd3[0] || hd3[2] == hd3[1]) hd3[2] = 0xFFFFFFFFu;
-            const uint64_t rest_rep = __builtin_amdgcn_ballot_w64(d0 == dn && d0 != hd3[0] && d0 != hd3[1] && d0 != hd3[2]) & ~1ull;
-            if ((hd3[0] & hd3[1] & hd3[2]) != 0xFFFFFFFFu && __builtin_popcountll(rest_rep) < 8) { heavy = true; careful = false; }
+            bool listed = false;
+#pragma unroll
+            for (int e = 0; e < NHEAVY; ++e) listed |= d0 == hd3[e];
+            const uint64_t rest_rep = __builtin_amdgcn_ballot_w64(d0 == dn && !listed) & ~1ull;
+            if (any && __builtin_popcountll(rest_rep) < 8) { heavy = true; careful = false; }
         }
         fast = !careful && full;  // any order inside a run will do (no order test) — but a partial tile's padding must stay BEHIND
                                   // the real keys of digit 255, which only the stable forms below guarantee
@@ -2035,14 +2045,14 @@ __global__ __launch_bounds__(NWAVES * 64, RDST_MSD_MINWAVES) void msd_scatter_ke
         } else if (fast && heavy) {
             // (the table is this wave's own: a heavy digit's lanes are ranked from a running count in a scalar register — no LDS
             // round trip between the rounds — and the count is stored once at the end; the other lanes' digits are other words)
-            uint32_t run3[3] = {0, 0, 0};
+            uint32_t run3[NHEAVY] = {0, 0, 0, 0, 0};
 #pragma unroll
             for (int i = 0; i < KPT; ++i) {
                 const uint32_t d = digit_of(mk[i], shift);
                 uint32_t r = 0;
                 bool ranked = false;
 #pragma unroll
-                for (int h = 0; h < 3; ++h) {
+                for (int h = 0; h < NHEAVY; ++h) {
                     const uint64_t m = __builtin_amdgcn_ballot_w64(d == hd3[h]);
                     if (d == hd3[h]) {
                         r = run3[h] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -2055,7 +2065,7 @@ __global__ __launch_bounds__(NWAVES * 64, RDST_MSD_MINWAVES) void msd_scatter_ke
                 else run_index[i >> 1] = r;
             }
 #pragma unroll
-            for (int h = 0; h < 3; ++h)
+            for (int h = 0; h < NHEAVY; ++h)
                 if (lane == 0 && hd3[h] != 0xFFFFFFFFu) wh[hd3[h]] = run3[h];
         } else if (fast) {
 #pragma unroll
