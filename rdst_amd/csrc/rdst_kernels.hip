@@ -459,8 +459,8 @@ constexpr uint32_t PRESAMPLE_TOP_LIMIT = 2 * PRESAMPLE_KEYS / RADIX;  // twice a
 
 template <typename K, bool MAPPED>
 __global__ __launch_bounds__(1024) void presample_kernel(const K* __restrict__ keys, uint64_t n, K neg, K pos, Plan* __restrict__ plan, uint32_t limit,
-                                                         uint32_t mid_lo /* 4-byte keys: buckets over this many keys ... */, uint32_t mid_hi /* ... and below this cost more than the LSD route saves (0: no such class) */,
-                                                         uint32_t giant_max /* 4-byte keys: count tables for buckets of mid_hi keys and more */, uint32_t bucket_cap /* 8-byte keys: the largest bucket K4 takes */) {
+                                                         uint32_t giant_min /* 4-byte keys: buckets of this many keys and more are the giant kernels' (0: no such kernels here) */,
+                                                         uint32_t giant_max /* 4-byte keys: count tables for that many such buckets */, uint32_t bucket_cap /* 8-byte keys: the largest bucket K4 takes */) {
     constexpr int W = sizeof(K) * 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* s_c = reinterpret_cast<uint32_t*>(smem);               // 65 536 8-bit counters, four per word
@@ -526,9 +526,8 @@ __global__ __launch_bounds__(1024) void presample_kernel(const K* __restrict__ k
         const uint32_t hits = s_top[tid];
         const uint64_t est = n * hits / ((uint64_t)PRESAMPLE_KEYS * RADIX);
         if constexpr (sizeof(K) == 4) {
-            // [6] samples in bytes whose buckets look like one to four tiles, [7] such bytes at giant size (256 giants each)
-            if (mid_hi && hits >= 8 && est > (uint64_t)mid_lo + mid_lo / 4 && est + est / 4 < (uint64_t)mid_hi) atomicAdd(&s_skew[6], hits);
-            if (mid_hi && hits >= 8 && est >= (uint64_t)mid_hi + mid_hi / 4) atomicAdd(&s_skew[7], 1u);
+            // [7] bytes whose buckets look giant-sized (256 giants each)
+            if (giant_min && hits >= 8 && est >= (uint64_t)giant_min + giant_min / 4) atomicAdd(&s_skew[7], 1u);
         } else {
             if (bucket_cap && hits >= 16 && est > (uint64_t)bucket_cap * 2) s_skew[3] = 1;  // some bucket of that byte is over the tile for sure
         }
@@ -536,7 +535,7 @@ __global__ __launch_bounds__(1024) void presample_kernel(const K* __restrict__ k
     __syncthreads();
     if (tid == 0) {
         bool lsd = false;
-        if constexpr (sizeof(K) == 4) lsd = mid_hi && ((uint64_t)s_skew[6] * 5 > (uint64_t)PRESAMPLE_KEYS * 2 || (uint64_t)s_skew[7] * RADIX > (uint64_t)giant_max + giant_max / 2);
+        if constexpr (sizeof(K) == 4) lsd = giant_min && (uint64_t)s_skew[7] * RADIX > (uint64_t)giant_max + giant_max / 2;
         else lsd = s_skew[3] != 0;
         if (lsd) plan->predict_lsd = 1;
     }
@@ -743,7 +742,6 @@ struct RouteArgs {
     Plan* plan;
     uint64_t n;
     uint32_t levels, cap, allow_skip;
-    uint32_t mid_tile;  // 4-byte keys: buckets over this many keys go to the expanding K4 (~7 ns per 1 000 keys against ~1.5); 0: no such buckets
     // 4-byte keys: buckets of 65 536 keys and more ("giants") are sorted by the giant kernels of K4 — at most giant_max of
     // them (a 256-KiB table each); 0: such a bucket sends the sort down the LSD route
     uint32_t giant_max;
@@ -773,7 +771,7 @@ constexpr uint32_t GIANT_OUT = 1u << 12;   // positions a block of the giant exp
 constexpr uint32_t GIANT_TABLE = H16_BINS + 16;  // words per giant: 65 536 counts / prefixes, then the total
 
 __global__ __launch_bounds__(1024) void route_kernel(RouteArgs a) {
-    __shared__ uint32_t s_wsum[16], s_wmax[16], s_wmid[16], s_wg[16], s_wci[16], s_wei[16], s_tiles[RADIX], s_tw[4];
+    __shared__ uint32_t s_wsum[16], s_wmax[16], s_wg[16], s_wci[16], s_wei[16], s_tiles[RADIX], s_tw[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (a.plan->route == ROUTE_ATOMIC) return;  // tried first, and it took the sort (msd_finish_kernel): nothing to decide
     if (a.plan->predict_lsd) return;            // K1h did not count: the route stays LSD (the cleared plan / msd_finish_kernel)
@@ -800,11 +798,6 @@ __global__ __launch_bounds__(1024) void route_kernel(RouteArgs a) {
         else mx = c[k] > mx ? c[k] : mx;
     }
     const uint32_t mine = sum0 + sum1;
-    uint32_t mid = 0;  // keys in buckets over the middle kernel's tile (they cannot pass 2^32 in sum: n < 2^32)
-    if (a.mid_tile) {
-#pragma unroll
-        for (int k = 0; k < 64; ++k) mid += (c[k] > a.mid_tile && !(giants_ok && c[k] >= GIANT_MIN)) ? c[k] : 0u;
-    }
     uint32_t incl = mine, wmax = mx, ig = ng;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -812,17 +805,14 @@ __global__ __launch_bounds__(1024) void route_kernel(RouteArgs a) {
         if (lane >= o) { incl += y; ig += yg; }
         const uint32_t m = __shfl_xor(wmax, o);
         wmax = m > wmax ? m : wmax;
-        mid += __shfl_xor(mid, o);
     }
     if (lane == 63) { s_wsum[wave] = incl; s_wg[wave] = ig; }
-    if (lane == 0) { s_wmax[wave] = wmax; s_wmid[wave] = mid; }
+    if (lane == 0) s_wmax[wave] = wmax;
     __syncthreads();
     uint32_t excl = incl - mine, bmax = 0, eg = ig - ng, tg = 0;
-    uint64_t bmid = 0;
     for (int w = 0; w < 16; ++w) {
         if (w < wave) { excl += s_wsum[w]; eg += s_wg[w]; }
         bmax = s_wmax[w] > bmax ? s_wmax[w] : bmax;
-        bmid += s_wmid[w];
         tg += s_wg[w];
     }
     // the giants' work items (the chunking depends on how many giants there are: a second scan)
@@ -850,10 +840,9 @@ __global__ __launch_bounds__(1024) void route_kernel(RouteArgs a) {
         if (w < wave) { eci += s_wci[w]; eei += s_wei[w]; }
         tci += s_wci[w]; tei += s_wei[w];
     }
-    // the expanding kernel costs ~7 ns per 1 000 keys; the LSD route costs ~3.4 more than the hybrid one per 1 000 keys of the
-    // slice: with more than a third of the keys in such buckets the LSD route is the faster one
-    const bool hybrid = *a.overflow == 0 && bmax <= a.cap && (giants_ok ? tg <= a.giant_max : a.plan->gross_skew == 0) &&
-                        bmid * 3 <= a.n;  // (gross skew without the giant kernels: K1h returned at once, its counts are all zero)
+    // (buckets over the counting K4's tile are no reason to leave: the expanding kernel takes 10^9 keys in such buckets in 2.3-2.8 ms,
+    // which keeps the hybrid route 0.7 ms and more ahead of the LSD one — round 2's form of it, at 7 ns per 1 000 keys, did not)
+    const bool hybrid = *a.overflow == 0 && bmax <= a.cap && (giants_ok ? tg <= a.giant_max : a.plan->gross_skew == 0);  // (gross skew without the giant kernels: K1h returned at once, its counts are all zero)
     if (tid == 0) {
         a.plan->route = hybrid ? ROUTE_HYBRID : ROUTE_LSD;
         if (a.pre_launch) a.plan->pre = 1;
@@ -1158,7 +1147,7 @@ __global__ __launch_bounds__(256 * SCAN_GROUPS) void scan_kernel(ScanArgs a) {
 #ifdef RDST_EXPERIMENTS
 __device__ uint32_t* g_exp_stats = nullptr;  // [tiles][4] look-back records of pass 0 (tools/ only)
 __device__ uint32_t* g_exp_timeline = nullptr;  // [tiles][12] shader-clock stamps of thread 0 along a tile of pass 0
-__device__ uint32_t g_exp_timeline_kernel = 0;  // whose stamps: 0 K3 (level 0), 1 local_wide2_sort_kernel, 2 / 3 msd_scatter_kernel pass A / B, 4 local_count_sort_kernel
+__device__ uint32_t g_exp_timeline_kernel = 0;  // whose stamps: 0 K3 (level 0), 1 local_wide2_sort_kernel, 2 / 3 msd_scatter_kernel pass A / B, 5 local_expand_sort_kernel
 #define RDST_STAMP(k) do { if (tl_on) tl[k] = (uint32_t)__builtin_amdgcn_s_memtime(); } while (0)
 // the same for the other kernels: RDST_TL_BEGIN(which) declares the record, RDST_TL_END(row) stores it (slots 10, 11: XCC id, block)
 #define RDST_TL_BEGIN(which) uint32_t tl[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; const bool tl_on = g_exp_timeline != nullptr && g_exp_timeline_kernel == (which) && threadIdx.x == 0; RDST_STAMP(0)
@@ -2861,13 +2850,13 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 8 : 6) void local_count_sort
 //   count     one LDS add per key on 65 536 16-bit counters (128 KiB; a wave whose 64 keys are one value adds once)
 //   scan      thread t owns 64 consecutive values (32 words, stored word-major so the sweep is conflict-free) and
 //             replaces the counts by exclusive prefixes
-//   expand    output position i holds the largest v with prefix[v] <= i: a 16-step search of the table, then one
-//             coalesced store of (bucket << 16 | v) with the key map undone
-// One block per CU walks the list.  Twice the LDS reads per key of the kernel above; it runs on what that one refuses:
-// skewed low halves (a bucket of 15 000 keys over 256 distinct values) and buckets of up to four tiles.
+//   expand    output position i holds the largest v with prefix[v] <= i: run starts marked in the (cleared) table, a
+//             max-scan over the positions, then 16-byte stores of (bucket << 16 | v) with the key map undone
+// One block per CU walks the list.  It runs on what the kernel above refuses: skewed low halves (a bucket of 15 000
+// keys over 256 distinct values) and buckets of up to four tiles.
 constexpr int EXPAND_THREADS = 1024;
 constexpr uint32_t EXPAND_MAX = 65535;  // keys per bucket
-constexpr int EXPAND_WORDS = H16_BINS / 2 + H16_BINS / 64;  // two counters per word, one pad word after every 32
+constexpr int EXPAND_WORDS = H16_BINS / 2 + H16_BINS / 64;  // two counters per word, one pad word after every 32 (a multiple of 4)
 constexpr size_t expand_lds_bytes() { return 4 * (size_t)EXPAND_WORDS + 128; }
 
 template <bool MAPPED, bool FROM16>
@@ -2885,10 +2874,37 @@ __global__ __launch_bounds__(EXPAND_THREADS) void local_expand_sort_kernel(
     // would hit two or four banks with a thread-major table)
     uint32_t* tab = reinterpret_cast<uint32_t*>(smem);
     uint32_t* s_wsum = reinterpret_cast<uint32_t*>(smem + 4 * (size_t)EXPAND_WORDS);  // [16]
+    uint32_t* s_wmax = s_wsum + 16;                                                    // [16]
+    uint16_t* tab16 = reinterpret_cast<uint16_t*>(smem);  // the table again, as what the expansion makes of it: one half per output position
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     auto word_of = [](uint32_t v) -> uint32_t { return (v >> 1) + (v >> 6); };
+    auto count_key = [&](uint32_t x, bool valid) {
+        const uint32_t x0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
+        if (__all((int)(valid && x == x0)) != 0) {  // 64 keys of one value: one add, not 64 on one address
+            if (lane == 0) atomicAdd(&tab[word_of(x0)], 64u << ((x0 & 1u) * 16u));
+        } else if (valid) {
+            atomicAdd(&tab[word_of(x)], 1u << ((x & 1u) * 16u));
+        }
+    };
+    auto clear_table = [&]() {
+        uint4* t4 = reinterpret_cast<uint4*>(tab);
+        for (int i = tid; i < EXPAND_WORDS / 4; i += BLOCK) t4[i] = make_uint4(0, 0, 0, 0);
+    };
     const uint32_t total = *list_count;
+    // FROM16: eight halves per load, four loads per thread in flight — a bucket of up to 32 768 keys is one round trip to memory
+    // (3.5 us of a 30 000-key bucket's 18, with the table cleared meanwhile.  Starting the next bucket's trip early — into
+    // registers, or one touch per 128-byte line for L2 — moved the wait to the next vmcnt the compiler placed and gained nothing.)
+    constexpr int U2 = 4;
+    uint4 q[U2];
+    auto load = [&](uint64_t base, uint64_t g1) {  // (src16's base is 16-byte aligned and its end padded)
+#pragma unroll
+        for (int j = 0; j < U2; ++j) {
+            const uint64_t p = base + ((uint64_t)j * BLOCK + (uint64_t)tid) * 8;
+            q[j] = p < g1 ? *reinterpret_cast<const uint4*>(src16 + p) : uint4{0, 0, 0, 0};
+        }
+    };
     for (uint32_t e = blockIdx.x; e < total; e += gridDim.x) {
+        RDST_TL_BEGIN(5u);
         const uint32_t bucket = list[e];
         const uint32_t start = bstart[bucket], cnt = slot_count ? slot_count[bucket] : bstart[bucket + 1] - start;
         const uint32_t soff = slot_count ? bucket * slot_cap : start;
@@ -2896,39 +2912,74 @@ __global__ __launch_bounds__(EXPAND_THREADS) void local_expand_sort_kernel(
             if (tid == 0) atomicOr(err, ERR_LOCAL_OVERFLOW);
             continue;
         }
-        for (int i = tid; i < EXPAND_WORDS; i += BLOCK) tab[i] = 0;
-        __syncthreads();
-        constexpr int U = 8;  // keys in flight per thread: the loads of a batch are issued together, so are the searches below
-        for (uint32_t base = 0; base < cnt; base += BLOCK * U) {  // wave-uniform trip count
-            uint32_t v[U];
+        // count: the table is cleared while the first loads are in flight
+        if constexpr (FROM16) {
+            const uint64_t g0 = soff, g1 = (uint64_t)soff + cnt;  // element range in src16
+            uint64_t base = g0 & ~7ull;
+            load(base, g1);
+            clear_table();
+            __syncthreads();
+            RDST_STAMP(1);
+            for (;;) {  // block-uniform trip count
 #pragma unroll
-            for (int j = 0; j < U; ++j) {
-                const uint32_t idx = base + (uint32_t)j * BLOCK + (uint32_t)tid;
-                const uint32_t at = idx < cnt ? idx : cnt - 1;
-                if constexpr (FROM16) v[j] = src16[soff + at];
-                else v[j] = buf[start + at];
-            }
+                for (int j = 0; j < U2; ++j) {
+                    const uint64_t p = base + ((uint64_t)j * BLOCK + (uint64_t)tid) * 8;
+                    const uint32_t w[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+                    const bool whole = p >= g0 && p + 8 <= g1;  // all eight halves are the bucket's
+                    const uint32_t x0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(w[0] & 0xFFFFu)), pair0 = x0 | (x0 << 16);
+                    if (__all((int)(whole && w[0] == pair0 && w[1] == pair0 && w[2] == pair0 && w[3] == pair0)) != 0) {
+                        if (lane == 0) atomicAdd(&tab[word_of(x0)], 512u << ((x0 & 1u) * 16u));  // 512 keys of one value: one add, not 512 on one address
+                    } else if (whole) {
 #pragma unroll
-            for (int j = 0; j < U; ++j) {
-                const uint32_t idx = base + (uint32_t)j * BLOCK + (uint32_t)tid;
-                const bool valid = idx < cnt;
-                const uint32_t x = FROM16 ? v[j] : ((MAPPED ? map_key<uint32_t>(v[j], neg, pos) : v[j]) & 0xFFFFu);
-                const uint32_t x0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
-                if (__all((int)(valid && x == x0)) != 0) {  // 64 keys of one value: one add, not 64 on one address
-                    if (lane == 0) atomicAdd(&tab[word_of(x0)], 64u << ((x0 & 1u) * 16u));
-                } else if (valid) {
-                    atomicAdd(&tab[word_of(x)], 1u << ((x & 1u) * 16u));
+                        for (int h = 0; h < 8; ++h) {
+                            const uint32_t x = (w[h >> 1] >> ((h & 1) * 16)) & 0xFFFFu;
+                            atomicAdd(&tab[word_of(x)], 1u + (x & 1u) * 0xFFFFu);
+                        }
+                    } else {
+#pragma unroll
+                        for (int h = 0; h < 8; ++h) {
+                            const uint32_t x = (w[h >> 1] >> ((h & 1) * 16)) & 0xFFFFu;
+                            if (p + h >= g0 && p + h < g1) atomicAdd(&tab[word_of(x)], 1u + (x & 1u) * 0xFFFFu);
+                        }
+                    }
                 }
+                base += (uint64_t)BLOCK * 8 * U2;
+                if (base >= g1) break;
+                load(base, g1);
+            }
+        } else {
+            clear_table();
+            __syncthreads();
+            RDST_STAMP(1);
+            constexpr int U = 8;  // keys in flight per thread
+            for (uint32_t base = 0; base < cnt; base += BLOCK * U) {  // wave-uniform trip count
+                uint32_t v[U];
+#pragma unroll
+                for (int j = 0; j < U; ++j) {
+                    const uint32_t idx = base + (uint32_t)j * BLOCK + (uint32_t)tid;
+                    v[j] = buf[start + (idx < cnt ? idx : cnt - 1)];
+                }
+#pragma unroll
+                for (int j = 0; j < U; ++j)
+                    count_key((MAPPED ? map_key<uint32_t>(v[j], neg, pos) : v[j]) & 0xFFFFu, base + (uint32_t)j * BLOCK + (uint32_t)tid < cnt);
             }
         }
+        RDST_STAMP(2);
         __syncthreads();
+        RDST_STAMP(3);
+        // scan: my 64 values' counts leave the table for registers (their words are cleared for the expansion below), `below` =
+        // the keys under my first value
+        uint32_t cw[WPT];
+        uint32_t below;
         {
             uint32_t run = 0;
 #pragma unroll
             for (int k = 0; k < WPT; ++k) {
-                const uint32_t w = tab[(WPT + 1) * tid + k];
-                run += (w & 0xFFFFu) + (w >> 16);
+                cw[k] = tab[(WPT + 1) * tid + k];
+                run += (cw[k] & 0xFFFFu) + (cw[k] >> 16);
             }
+#pragma unroll
+            for (int k = 0; k <= WPT; ++k) tab[(WPT + 1) * tid + k] = 0;  // (with the pad word: the expansion's 33rd)
             uint32_t incl = run;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
@@ -2937,42 +2988,103 @@ __global__ __launch_bounds__(EXPAND_THREADS) void local_expand_sort_kernel(
             }
             if (lane == 63) s_wsum[wave] = incl;
             __syncthreads();
-            uint32_t below = incl - run;
+            below = incl - run;
 #pragma unroll
             for (int x = 0; x < BLOCK / 64; ++x)
                 if (x < wave) below += s_wsum[x];
+        }
+        RDST_STAMP(4);
+        // expand (round 3 form): the value at output position p is the largest v with prefix[v] <= p, and values grow with the
+        // position, so it is a running maximum over marked run starts.  Every value that has keys writes itself at the position
+        // its run starts at (16 bits per position in the cleared table: 0 = no mark, and value 0 can only start at the first
+        // position, where nothing lies below it); a max-scan — thread t owns 66 positions, its 33 words, conflict-free as
+        // above — spreads the marks, in place; then the sorted halves are read back four at a time and leave as whole keys
+        // in 16-byte stores (positions are counted from the 16-byte boundary below the bucket's first key: q = p + mis).
+        // ~2 LDS operations and ~20 vector instructions per key, all of them with every lane busy (round 2 searched the table
+        // per position, 16 dependent LDS reads: 37 us of a 30 000-key bucket's 50).
+        uint32_t* tdst = buf + start;
+        const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(tdst) >> 2) & 3u;
+        const uint32_t q_end = cnt + mis;  // <= 65 538 <= 66 positions x 1 024 threads
+        {
+            uint32_t at = below + mis;
 #pragma unroll
-            for (int k = 0; k < WPT; ++k) {  // (every prefix is at most cnt <= 65 535: 16 bits hold it)
-                const uint32_t w = tab[(WPT + 1) * tid + k];
-                const uint32_t lo = below, hi = below + (w & 0xFFFFu);
-                below = hi + (w >> 16);
-                tab[(WPT + 1) * tid + k] = lo | (hi << 16);
+            for (int k = 0; k < WPT; ++k) {
+                const uint32_t c0 = cw[k] & 0xFFFFu, c1 = cw[k] >> 16;
+                const uint32_t v0 = 64u * (uint32_t)tid + 2u * (uint32_t)k;
+                if (c0) tab16[at] = (uint16_t)v0;
+                at += c0;
+                if (c1) tab16[at] = (uint16_t)(v0 + 1u);
+                at += c1;
             }
         }
         __syncthreads();
-        const uint32_t top = bucket_prefix16(plan, bucket) << 16;
-        for (uint32_t base = 0; base < cnt; base += BLOCK * U) {
-            uint32_t v[U];
+        constexpr uint32_t WAVE_POSITIONS = 64u * 2u * (WPT + 1);
+        const bool scans = (uint32_t)wave * WAVE_POSITIONS < q_end;  // wave-uniform: my wave's positions hold keys
+        {
+            uint32_t m = 0;
+            if (scans) {
 #pragma unroll
-            for (int j = 0; j < U; ++j) v[j] = 0;  // prefix[0] == 0 <= every position
-#pragma unroll
-            for (int b = 15; b >= 0; --b) {
-#pragma unroll
-                for (int j = 0; j < U; ++j) {  // (positions past the bucket's end search too, and find its last value: harmless)
-                    const uint32_t idx = base + (uint32_t)j * BLOCK + (uint32_t)tid;
-                    const uint32_t c = v[j] | (1u << b);
-                    const uint32_t p = (tab[word_of(c)] >> ((c & 1u) * 16u)) & 0xFFFFu;
-                    if (p <= idx) v[j] = c;
+                for (int k = 0; k <= WPT; ++k) {
+                    const uint32_t w = tab[(WPT + 1) * tid + k];
+                    const uint32_t lo = w & 0xFFFFu, hi = w >> 16;
+                    m = lo > m ? lo : m;
+                    const uint32_t first = m;
+                    m = hi > m ? hi : m;
+                    if (k < WPT) cw[k] = first | (m << 16);
+                    else below = first | (m << 16);
                 }
             }
+            uint32_t incl = m;
 #pragma unroll
-            for (int j = 0; j < U; ++j) {
-                const uint32_t idx = base + (uint32_t)j * BLOCK + (uint32_t)tid;
-                const uint32_t m = top | v[j];
-                if (idx < cnt) buf[start + idx] = MAPPED ? unmap_key<uint32_t>(m, neg, pos) : m;
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t y = __shfl_up(incl, o);
+                if (lane >= o && y > incl) incl = y;
+            }
+            if (lane == 63) s_wmax[wave] = incl;
+            uint32_t carry = __shfl_up(incl, 1);
+            if (lane == 0) carry = 0;
+            __syncthreads();
+            if (scans) {
+#pragma unroll
+                for (int x = 0; x < BLOCK / 64; ++x)
+                    if (x < wave && s_wmax[x] > carry) carry = s_wmax[x];
+                // (marks grow with the position: my positions before my first mark take the carry, the others are above it already)
+#pragma unroll
+                for (int k = 0; k <= WPT; ++k) {
+                    const uint32_t w = k < WPT ? cw[k] : below;
+                    const uint32_t lo = w & 0xFFFFu, hi = w >> 16;
+                    tab[(WPT + 1) * tid + k] = (lo > carry ? lo : carry) | ((hi > carry ? hi : carry) << 16);
+                }
             }
         }
+        __syncthreads();
+        {
+            const uint32_t top = bucket_prefix16(plan, bucket) << 16;
+            uint4* gq = reinterpret_cast<uint4*>(tdst - mis);  // quad j = shifted positions 4 j .. 4 j + 3, 16-byte aligned
+            const uint2* lq = reinterpret_cast<const uint2*>(tab16);
+            const uint32_t quads = (q_end + 3u) >> 2;
+            for (uint32_t j = tid; j < quads; j += BLOCK) {
+                const uint2 m = lq[j];
+                uint32_t k4[4] = {top | (m.x & 0xFFFFu), top | (m.x >> 16), top | (m.y & 0xFFFFu), top | (m.y >> 16)};
+                if constexpr (MAPPED) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) k4[c] = unmap_key<uint32_t>(k4[c], neg, pos);
+                }
+                const uint32_t q0 = 4u * j;
+                if (q0 >= mis && q0 + 3u < q_end) {
+                    gq[j] = make_uint4(k4[0], k4[1], k4[2], k4[3]);
+                } else {  // the bucket's first and last quad
+                    uint32_t* g = reinterpret_cast<uint32_t*>(gq + j);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (q0 + (uint32_t)c >= mis && q0 + (uint32_t)c < q_end) g[c] = k4[c];
+                }
+            }
+        }
+        RDST_STAMP(5);
         __syncthreads();  // the next bucket clears the table
+        RDST_STAMP(6); RDST_STAMP(7); RDST_STAMP(8);
+        RDST_TL_END(e);
     }
 }
 
@@ -4523,17 +4635,17 @@ int launch_presample(const K* keys, uint64_t n, KeyMap km, Plan* plan, hipStream
     const bool mapped = km.neg != 0 || km.pos != 0;
     const uint32_t limit = 12u + (uint32_t)(4ull * (uint64_t)local_tile(sizeof(K)) * PRESAMPLE_KEYS / n);
     constexpr size_t plds = presample_lds_bytes();
-    // what route_kernel will hold against the exact counts (RouteArgs::mid_tile, giant_max, cap), for the sample's prediction
+    // what route_kernel will hold against the exact counts (RouteArgs::giant_max, cap), for the sample's prediction
     const bool big4 = sizeof(K) == 4 && g_tuning.count_sort && g_tuning.expand && g_tuning.predict;
-    const uint32_t mid_lo = big4 ? (uint32_t)COUNT16_TILE : 0u, mid_hi = big4 ? GIANT_MIN : 0u;
+    const uint32_t giant_min = big4 ? GIANT_MIN : 0u;
     const uint32_t giant_max = big4 && g_tuning.giants && n < (1ull << 30) ? GIANT_MAX : 0u;
     const uint32_t bucket_cap = sizeof(K) == 8 && g_tuning.predict ? (uint32_t)local_tile(8) : 0u;
     if (mapped) {
         if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&presample_kernel<K, true>), plds)) return rc;
-        hipLaunchKernelGGL((presample_kernel<K, true>), dim3(1), dim3(1024), plds, s, keys, n, (K)km.neg, (K)km.pos, plan, limit, mid_lo, mid_hi, giant_max, bucket_cap);
+        hipLaunchKernelGGL((presample_kernel<K, true>), dim3(1), dim3(1024), plds, s, keys, n, (K)km.neg, (K)km.pos, plan, limit, giant_min, giant_max, bucket_cap);
     } else {
         if (int rc = ensure_lds_attr(reinterpret_cast<const void*>(&presample_kernel<K, false>), plds)) return rc;
-        hipLaunchKernelGGL((presample_kernel<K, false>), dim3(1), dim3(1024), plds, s, keys, n, (K)km.neg, (K)km.pos, plan, limit, mid_lo, mid_hi, giant_max, bucket_cap);
+        hipLaunchKernelGGL((presample_kernel<K, false>), dim3(1), dim3(1024), plds, s, keys, n, (K)km.neg, (K)km.pos, plan, limit, giant_min, giant_max, bucket_cap);
     }
     HIP_TRY(hipGetLastError());
     return RDST_OK;
@@ -4954,7 +5066,6 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
         ra.glist = reinterpret_cast<uint32_t*>(ws + L.off_glist);
         ra.gcount_item = ra.glist + GIANT_MAX + 16;
         ra.gexp_item = ra.gcount_item + GIANT_MAX + 16;
-        ra.mid_tile = ra.cap == EXPAND_MAX && n >= (1u << 24) ? (uint32_t)COUNT16_TILE : 0u;  // (short slices: the test is not worth a wrong guess either way)
         ra.pre_launch = pre_launch;
         ra.msd_tile = (uint32_t)(MSD_WAVES * 64 * msd_kpt(sizeof(K)));
         ra.cursor_a = reinterpret_cast<uint32_t*>(ws + L.off_cursor_a);

@@ -16,9 +16,15 @@ g = torch.Generator(device="cuda").manual_seed(1)
 if name == "float32n":   # a float column: normal(0, 1), sorted as f32 (the hybrid route's exact MSD passes)
     name, it = "float32", torch.int32
     src = torch.randn(n, dtype=torch.float32, device="cuda", generator=g).view(torch.int32)
+elif name == "uint32g":  # a bell over the whole range (sum of four uniforms): three quarters of the keys in buckets of 17 409 .. 45 000
+    name, it = "uint32", torch.int32
+    r0 = torch.randint(-(2**31), 2**31, (n,), dtype=torch.int32, device="cuda", generator=g)
+    src = (r0 >> 2) + (torch.roll(r0, 1) >> 2) + (torch.roll(r0, 2) >> 2) + (torch.roll(r0, 3) >> 2)
+    del r0
 else:
     it = torch.int32 if name == "uint32" else torch.int64
     info = torch.iinfo(it)
+if "src" not in dir():
     src = torch.randint(info.min, info.max, (n,), dtype=it, device="cuda", generator=g)
 keys, tmp = src.clone(), torch.empty_like(src)
 view, tview = keys.view(getattr(torch, name)), tmp.view(getattr(torch, name))
@@ -35,7 +41,8 @@ r = rec[rec[:, last] != 0].astype(np.int64)
 names = {1: ["loads issued + tables zeroed", "barrier (loads land)", "count (returning LDS adds)", "barrier + scan + prefixes + barrier", "place (slots, staged bits)",
              "barrier + ties", "barrier + stage half 0 + barrier", "store half 0 + barrier", "stage + store half 1"],
          2: ["loads issued", "loads land + inversion test + count", "barrier", "digit sums + scan + claims", "barrier", "place into LDS", "barrier", "scatter stores issued"],
-         3: ["loads issued", "loads land + count", "barrier", "digit sums + scan + claims", "barrier", "place into LDS", "barrier", "scatter stores issued"]}[which]
+         3: ["loads issued", "loads land + count", "barrier", "digit sums + scan + claims", "barrier", "place into LDS", "barrier", "scatter stores issued"],
+         5: ["table zeroed + barrier", "loads + count", "barrier", "scan + prefixes + barrier", "expand (windows)", "barrier", "-", "-"]}[which]
 d = (r[:, 1:last + 1] - r[:, 0:last]) & 0xFFFFFFFF
 print(f"{name} kernel {which}: {len(r)} workgroups; shader clocks per phase as thread 0 sees them (mean / p50 / p90), us at 2.4 GHz:")
 for k, nm in enumerate(names):
