@@ -321,7 +321,7 @@ int rdst_hip_profile_run_stages(int run, uint32_t* stages_out, uint32_t capacity
  * every width with one detail changed, for A/B runs and tests — 2: ranked in-LDS sort for 4-byte keys as well, 3: pass L-1
  * hands K4 whole keys instead of 16-bit halves, 5: no key sample, 6: 8-byte keys with the one-block-per-CU form of K4, 9: no
  * expanding K4 (4-byte buckets up to one tile only); 8: the atomic route for 4-byte keys only; 10: a failed atomic route
- * falls straight to LSD; 11: no giant kernels.  min_len == 0 keeps the built-in threshold (2^28).  Results are identical
+ * falls straight to LSD; 11: no giant kernels.  min_len == 0 keeps the built-in thresholds (atomic route: 3 * 2^26 4-byte keys, 2^26 8-byte keys; K1h hybrid route: 2^28).  Results are identical
  * on every route.  Not part of the reference surface. */
 int rdst_hip_set_hybrid(int enabled, uint64_t min_len);
 

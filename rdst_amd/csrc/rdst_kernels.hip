@@ -80,7 +80,7 @@ constexpr uint32_t ERR_LOCAL_OVERFLOW = 4;  // a bucket larger than the K4 kerne
 // Three routes through the kernels, chosen ON THE DEVICE from a sample and the counts of the key multiset — the device
 // form of Tuner::pick_algorithm(params, counts) (src/tuner.rs:33-35, src/sorter.rs:67-76).  Tried in this order; the
 // host launches every kernel of every route, each looks at the plan first:
-//   ROUTE_ATOMIC  (4- and 8-byte keys, 2^28 <= n < 2^30) the hybrid route without its counting read.  An MSD pass needs no
+//   ROUTE_ATOMIC  (4- and 8-byte keys, atomic_min_len() <= n < 2^30) the hybrid route without its counting read.  An MSD pass needs no
 //                 stable order and no exact global offsets up front, only ROOM: pass A scatters by the top byte into
 //                 256 x 8 over-provisioned areas (XCD slice x digit) of the workspace, a tile claiming its space per digit
 //                 with ONE returning global atomic where K3 walks back over its predecessors; pass B scatters every area by
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const K* __restrict_
 // Cost: ~10 us per hybrid-eligible sort (one batch of eight loads per thread).
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t PRESAMPLE_KEYS = 8192;  // 65 536 spread-out keys cost 0.17 ms (a TLB miss each); 8 192 in one batch of loads: ~0.01 ms
-constexpr uint64_t PRESAMPLE_MIN_LEN = 1ull << 28;  // below it a full tile expects more hits than 8-bit counters and a small limit allow
+constexpr uint64_t PRESAMPLE_MIN_LEN = 1ull << 26;  // the shortest slice a byte-saving route is tried on by default (atomic_min_len): a full tile expects 2 hits there, the limit is 20
 constexpr size_t presample_lds_bytes() { return 2 * H16_BINS + 32 + 4 * RADIX; }
 // low halves of the sample that were seen before: S - D (1 - exp(-S / D)) for S = 8 192 samples over D equally likely values:
 // ~490 on uniform keys (D = 65 536), 3 000 for D = 8 192, 5 000 for D ~ 3 500 — where a bucket of 15 000 keys holds each value
@@ -1009,6 +1009,7 @@ struct ScanArgs {
     uint64_t n, hist_piece;
     uint32_t levels, allow_skip, level_lo, level_hi, hist_grid, tile, use_chains;
     uint32_t halves;  // hybrid route hands K4 the 16-bit halves pass L-1 writes: that pass must run even if its level is trivial
+    uint32_t deliver_tmp;  // the caller wants the result in tmp (run_split_sort's parts): a K4 that writes whole keys from the workspace writes them there
 };
 
 constexpr int SCAN_GROUPS = 4;  // levels handled side by side, 256 threads (one per digit) each
@@ -1077,7 +1078,9 @@ __global__ __launch_bounds__(256 * SCAN_GROUPS) void scan_kernel(ScanArgs a) {
         }
         // (hybrid route with the 16-bit hand-off: K4 reads the halves from the workspace and writes whole keys — to the caller's
         // array, whichever buffer the last pass read: no copy-back even after an odd number of passes)
-        a.plan->result_in_tmp = hybrid && a.halves ? 0u : in_tmp;
+        // (the atomic route's K4 reads its slots: the same, and either buffer is as good a destination — deliver_tmp picks)
+        const bool from_workspace = (hybrid && a.halves) || atomic_done;
+        a.plan->result_in_tmp = from_workspace ? ((a.deliver_tmp && a.plan->local_sort) ? 1u : 0u) : in_tmp;
         a.plan->executed = executed;
     }
     __syncthreads();
@@ -4098,10 +4101,11 @@ __global__ __launch_bounds__(WIDE3_THREADS, 8) void local_wide3_sort_kernel(
 
 // result sits in tmp after an odd number of executed passes: copy back
 // (src/sorts/lsb_sort.rs:117-126)
+// (want_tmp: the other way round — `keys` is the caller's tmp, `tmp` its keys, and the copy runs when the result is NOT in tmp)
 template <typename K, int VEC>
 __global__ __launch_bounds__(256) void copyback_kernel(K* __restrict__ keys, const K* __restrict__ tmp,
-                                                       uint64_t n, const Plan* __restrict__ plan) {
-    if (!plan->result_in_tmp) return;
+                                                       uint64_t n, const Plan* __restrict__ plan, uint32_t want_tmp) {
+    if ((plan->result_in_tmp != 0u) == (want_tmp != 0u)) return;
     struct alignas(sizeof(K) * VEC) V { K e[VEC]; };
     const uint64_t nvec = n / VEC;
     const uint64_t stride = (uint64_t)gridDim.x * 256;
@@ -4336,8 +4340,10 @@ struct Tuning {
     bool expand = true;                 // 4-byte keys: buckets the counting K4 refuses go to the expanding one (any bucket below 65 536 keys)
     bool atomic_wide = true;            // ROUTE_ATOMIC for 8-byte keys too (whole keys in the slots)
     bool persist_fallback = true;       // behind the atomic route the LSD passes run as persistent blocks (cheap to skip)
+    bool split_always = false;          // ... at every length, in eight parts (tests)
+    bool split = true;                  // 8-byte keys beyond the atomic route's window: one exact pass on the top byte, then its groups as slices of their own (run_split_sort)
     bool predict = true;                // the sample may predict the LSD route (Plan::predict_lsd): neither MSD passes nor K1h are tried
-    uint64_t hybrid_min_len = 1ull << 28;  // below this the buckets are too small for one workgroup each to pay off
+    uint64_t hybrid_min_len = 0;        // rdst_hip_set_hybrid's min_len; 0: the measured defaults below (atomic_min_len, hybrid_min_len)
 };
 uint32_t g_ablate = 0;  // only ever set by the RDST_EXPERIMENTS build
 #ifdef RDST_EXPERIMENTS
@@ -4564,9 +4570,16 @@ int prof_mark(DeviceState& D, hipStream_t s, uint32_t kind = 0) {
     return RDST_OK;
 }
 
+// Below these lengths the buckets are too small for one workgroup each to pay off: K4 has a floor of 65 536 workgroups' fixed
+// costs (0.61 ms for 4-byte keys, 1.17 ms for 8-byte keys, whatever n: tools/window_probe.py).  The atomic route passes the
+// LSD one at ~1.6 x 10^8 u32 keys (2 x 10^8: 1.44 against 1.58 ms) and at ~5 x 10^7 u64 keys (2^26: 1.87 against 2.19 ms; 2^27:
+// 2.36 against 4.10); the K1h hybrid route (one more read, exact passes) keeps round 2's 2^28.
+uint64_t atomic_min_len(size_t key_bytes) { return g_tuning.hybrid_min_len ? g_tuning.hybrid_min_len : (key_bytes == 8 ? 1ull << 26 : 3ull << 26); }
+uint64_t hybrid_min_len() { return g_tuning.hybrid_min_len ? g_tuning.hybrid_min_len : 1ull << 28; }
+
 // ROUTE_ATOMIC: 4- and 8-byte keys, and a length at which a uniform bucket (n / 65 536 keys) stays 8 sigma below the K4 tile
 bool atomic_eligible(uint64_t n, size_t key_bytes, int cfg) {
-    if (!g_tuning.hybrid || !g_tuning.atomic_route || n < g_tuning.hybrid_min_len || n >= (1ull << 30)) return false;
+    if (!g_tuning.hybrid || !g_tuning.atomic_route || n < atomic_min_len(key_bytes) || n >= (1ull << 30)) return false;
     if (key_bytes == 4 ? cfg != 4 : (key_bytes != 8 || !g_tuning.atomic_wide || !g_tuning.count_sort || !g_tuning.wide2)) return false;
     const double mean = (double)n / H16_BINS;
     return mean + 8.0 * __builtin_sqrt(mean) <= (double)local_tile(key_bytes);
@@ -4574,7 +4587,7 @@ bool atomic_eligible(uint64_t n, size_t key_bytes, int cfg) {
 
 bool hybrid_eligible(uint64_t n, size_t key_bytes) {
     const uint64_t cap = key_bytes == 4 && g_tuning.count_sort && g_tuning.expand ? EXPAND_MAX : (uint64_t)local_tile(key_bytes);
-    return g_tuning.hybrid && (key_bytes == 4 || key_bytes == 8) && n >= g_tuning.hybrid_min_len && n <= (uint64_t)H16_BINS * cap &&
+    return g_tuning.hybrid && (key_bytes == 4 || key_bytes == 8) && n >= hybrid_min_len() && n <= (uint64_t)H16_BINS * cap &&
            n < (1ull << 32);
 }
 
@@ -4930,14 +4943,15 @@ int launch_pass_pairs(K* keys, K* tmp, V* vals, V* vtmp, uint64_t n, int level, 
 template <typename K, int LEVELS, typename V = NoVal>
 int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level_lo, uint32_t level_hi,
                  bool allow_skip, bool copy_back, hipStream_t s, Layout* layout_out, char** ws_out, V* vals = nullptr,
-                 V* vtmp = nullptr) {
+                 V* vtmp = nullptr, bool deliver_tmp = false /* whole key-only sorts: leave the result in tmp, not in keys */) {
     constexpr bool HAS_V = ValBytes<V>::value != 0;
+    if (deliver_tmp && (HAS_V || !copy_back)) return fail(RDST_ERR_ARG, "deliver_tmp: whole key-only sorts");
     DeviceState* D;
     int rc = current_device_state(&D);
     if (rc) return rc;
     if constexpr (!HAS_V) {
         // a slice of at most one small tile: the one-workgroup sort, in place, no workspace
-        if (g_tuning.small_sort && level_lo == 0 && level_hi == (uint32_t)LEVELS && allow_skip && copy_back && !layout_out &&
+        if (g_tuning.small_sort && level_lo == 0 && level_hi == (uint32_t)LEVELS && allow_skip && copy_back && !layout_out && !deliver_tmp &&
             n <= (uint64_t)SMALL_THREADS * small_kpt(sizeof(K))) {
             const KeyMap km = key_map_for(kind, sizeof(K));
             const size_t lds = (size_t)SMALL_WAVES * 1024 + 16 + sizeof(K) * SMALL_THREADS * small_kpt(sizeof(K));
@@ -5195,6 +5209,7 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     sa.tile = L.tile;
     sa.use_chains = g_tuning.chains ? 1u : 0u;
     sa.halves = halves ? 1u : 0u;
+    sa.deliver_tmp = deliver_tmp ? 1u : 0u;
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(256 * SCAN_GROUPS), 0, s, sa);
     HIP_TRY(hipGetLastError());
     if ((rc = prof_mark(*D, s, RDST_STAGE_SCAN))) return rc;
@@ -5236,10 +5251,12 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
         if (cblocks < 1) cblocks = 1;
         const Plan* plan = reinterpret_cast<const Plan*>(ws + L.off_plan);
         constexpr int VEC = 16 / sizeof(K);
+        K* cdst = deliver_tmp ? tmp : keys;
+        const K* csrc = deliver_tmp ? keys : tmp;
         if (aligned)
-            hipLaunchKernelGGL((copyback_kernel<K, VEC>), dim3((uint32_t)cblocks), dim3(256), 0, s, keys, tmp, n, plan);
+            hipLaunchKernelGGL((copyback_kernel<K, VEC>), dim3((uint32_t)cblocks), dim3(256), 0, s, cdst, csrc, n, plan, deliver_tmp ? 1u : 0u);
         else
-            hipLaunchKernelGGL((copyback_kernel<K, 1>), dim3((uint32_t)cblocks), dim3(256), 0, s, keys, tmp, n, plan);
+            hipLaunchKernelGGL((copyback_kernel<K, 1>), dim3((uint32_t)cblocks), dim3(256), 0, s, cdst, csrc, n, plan, deliver_tmp ? 1u : 0u);
         HIP_TRY(hipGetLastError());
         if constexpr (HAS_V) {
             const bool valigned = ((reinterpret_cast<uintptr_t>(vals) | reinterpret_cast<uintptr_t>(vtmp)) & 15u) == 0;
@@ -5248,9 +5265,9 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
             if (vblocks < 1) vblocks = 1;
             constexpr int VVEC = 16 / sizeof(V);
             if (valigned)
-                hipLaunchKernelGGL((copyback_kernel<V, VVEC>), dim3((uint32_t)vblocks), dim3(256), 0, s, vals, vtmp, n, plan);
+                hipLaunchKernelGGL((copyback_kernel<V, VVEC>), dim3((uint32_t)vblocks), dim3(256), 0, s, vals, vtmp, n, plan, 0u);
             else
-                hipLaunchKernelGGL((copyback_kernel<V, 1>), dim3((uint32_t)vblocks), dim3(256), 0, s, vals, vtmp, n, plan);
+                hipLaunchKernelGGL((copyback_kernel<V, 1>), dim3((uint32_t)vblocks), dim3(256), 0, s, vals, vtmp, n, plan, 0u);
             HIP_TRY(hipGetLastError());
         }
         if ((rc = prof_mark(*D, s, RDST_STAGE_COPYBACK))) return rc;
@@ -5260,6 +5277,75 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     D->last_plan_valid = true;
     D->last_plan_off = L.off_plan;
     return workspace_release(*D, s);
+}
+
+// 8-byte keys beyond the atomic route's window (a uniform bucket of n / 65 536 keys no longer fits K4's tile: n > 1.04 x 10^9):
+// the reference recurses where a bucket is too big for the sort at hand (src/sorter.rs:131-138,
+// src/sorts/recombinating_sort.rs:68-88).  One exact scatter pass on the top byte (K1 counts that level, K3 moves the keys:
+// keys -> tmp, 24 bytes per key), its 256 counts come to the host, and aligned groups of top bytes — halved until the group
+// fits the window — are sorted as slices of their own: their keys share the group's top bits, so the sample lowers the window
+// past them and the atomic route takes the part as it takes a 10^9-key slice (48 bytes per key, result written straight into
+// the caller's array: deliver_tmp).  72 bytes per key where the LSD route moves 136.  A single top byte over the window is
+// sorted by whatever run_pipeline picks for it (skewed keys: the LSD route).
+bool split_eligible(uint64_t n, size_t key_bytes, int levels) {
+    if (key_bytes != 8 || levels != 8 || !g_tuning.split || !g_tuning.hybrid || !g_tuning.atomic_route || !g_tuning.atomic_wide || !g_tuning.count_sort || !g_tuning.wide2) return false;
+    if (g_tuning.split_always) return n >= 2 && n < (1ull << 36);
+    return n >= atomic_min_len(8) && !atomic_eligible(n, 8, default_cfg(8, n, true)) && n < (1ull << 36);
+}
+
+template <typename K, int LV>
+int run_split_sort(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, hipStream_t s) {
+    Layout L{};
+    char* ws = nullptr;
+    int rc = run_pipeline<K, LV>(keys, tmp, n, kind, LV - 1, LV, false, false, s, &L, &ws);
+    if (rc) return rc;
+    uint64_t counts[RADIX];
+    HIP_TRY(hipMemcpyAsync(counts, ws + L.off_hist + sizeof(uint64_t) * (size_t)(LV - 1) * RADIX, sizeof counts, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    uint64_t start[RADIX + 1];
+    start[0] = 0;
+    for (int d = 0; d < RADIX; ++d) start[d + 1] = start[d] + counts[d];
+    if (start[RADIX] != n) return fail(RDST_ERR_DEVICE, "split pass: the top level's counts do not add up");
+    struct Part { uint64_t off, cnt; };
+    std::vector<Part> parts;
+    // [lo, hi): an aligned group of top bytes.  A leaf: fits the window, or is too short to gain from a finer split, or one byte.
+    auto leaf = [&](uint64_t cnt, int width) {
+        if (g_tuning.split_always) return width <= 32;  // (tests: eight parts whatever the length)
+        return width == 1 || cnt < 2 * atomic_min_len(sizeof(K)) || atomic_eligible(cnt, sizeof(K), default_cfg(sizeof(K), cnt, kind != RDST_KEY_UNSIGNED));
+    };
+    struct Range { int lo, hi; };
+    std::vector<Range> todo{{0, RADIX}};
+    while (!todo.empty()) {
+        const Range r = todo.back();
+        todo.pop_back();
+        const uint64_t cnt = start[r.hi] - start[r.lo];
+        if (cnt == 0) continue;
+        if (leaf(cnt, r.hi - r.lo)) {
+            parts.push_back({start[r.lo], cnt});
+        } else {
+            const int mid = (r.lo + r.hi) / 2;
+            todo.push_back({mid, r.hi});
+            todo.push_back({r.lo, mid});
+        }
+    }
+    for (const Part& p : parts) {
+        if (p.cnt == 1) {
+            HIP_TRY(hipMemcpyAsync(keys + p.off, tmp + p.off, sizeof(K), hipMemcpyDeviceToDevice, s));
+            continue;
+        }
+        // the part lies in tmp (the split pass put it there); the caller's array is its scratch and its destination
+        rc = run_pipeline<K, LV, NoVal>(tmp + p.off, keys + p.off, p.cnt, kind, 0, LV, true, true, s, nullptr, nullptr, static_cast<NoVal*>(nullptr), static_cast<NoVal*>(nullptr), true);
+        if (rc) return rc;
+    }
+    return RDST_OK;
+}
+
+template <typename K, int LV>
+int sort_whole(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, hipStream_t s) {
+    if constexpr (sizeof(K) == 8) {
+        if (split_eligible(n, sizeof(K), LV)) return run_split_sort<K, LV>(keys, tmp, n, kind, s);
+    }
+    return run_pipeline<K, LV>(keys, tmp, n, kind, 0, LV, true, true, s, nullptr, nullptr);
 }
 
 template <typename K, int LV>
@@ -5494,8 +5580,10 @@ int rdst_hip_set_hybrid(int enabled, uint64_t min_len) {
     g_tuning.expand = enabled != 9;        // 9: the K1h hybrid route without the expanding K4 (buckets up to one tile; refused buckets to the ranked kernel) (A/B, tests)
     g_tuning.atomic_wide = enabled != 8;   // 8: the atomic route for 4-byte keys only, 8-byte keys on the K1h hybrid route (A/B, tests)
     g_tuning.predict = enabled != 14;      // 14: the default without the sample's prediction of the LSD route (A/B, tests)
-    g_tuning.atomic_route = g_tuning.atomic_route || enabled == 14 || enabled == 15;
-    g_tuning.hybrid_min_len = min_len ? min_len : (1ull << 28);
+    g_tuning.split = enabled != 16;        // 16: the default without the split of 8-byte slices beyond the atomic route's window (they take the LSD route) (A/B, tests)
+    g_tuning.split_always = enabled == 17; // 17: the default with that split at every length, in eight parts (tests)
+    g_tuning.atomic_route = g_tuning.atomic_route || enabled == 14 || enabled == 15 || enabled == 16 || enabled == 17;
+    g_tuning.hybrid_min_len = min_len;
     return RDST_OK;
 }
 
@@ -5686,7 +5774,14 @@ uint64_t rdst_hip_workspace_bytes(uint64_t len, uint32_t elem_bytes) {
     const bool msd = atomic_eligible(len, elem_bytes, cfg);
     const bool halves = !msd && elem_bytes == 4 && hybrid_eligible(len, 4) && g_tuning.halves && g_tuning.count_sort && cfg == 4 && len < (1ull << 30);
     const bool giants = elem_bytes == 4 && hybrid_eligible(len, 4) && g_tuning.giants && g_tuning.count_sort && g_tuning.expand && len < (1ull << 30);
-    return make_layout(len, elem_bytes, elem_bytes, cfg, 0, halves, msd, giants).total;
+    const uint64_t whole = make_layout(len, elem_bytes, elem_bytes, cfg, 0, halves, msd, giants).total;
+    if (split_eligible(len, elem_bytes, (int)elem_bytes)) {  // the split pass's tables for the whole slice, then a part's areas and slots (a part is at most the window)
+        uint64_t part = len < (1ull << 30) ? len : (1ull << 30) - 1;
+        while (part > (1ull << 26) && !atomic_eligible(part, 8, default_cfg(8, part, true))) part -= part / 64;
+        const uint64_t of_part = make_layout(part, 8, 8, default_cfg(8, part, true), 0, false, true, false).total;
+        return whole > of_part ? whole : of_part;
+    }
+    return whole;
 }
 
 int rdst_hip_sort_device(void* dev_keys, void* dev_tmp, uint64_t len, uint32_t elem_bytes, rdst_key_kind kind,
@@ -5698,7 +5793,7 @@ int rdst_hip_sort_device(void* dev_keys, void* dev_tmp, uint64_t len, uint32_t e
     if (reinterpret_cast<uintptr_t>(dev_tmp) % elem_bytes) return fail(RDST_ERR_ALIGN, "tmp pointer not aligned to the element size");
     std::lock_guard<std::mutex> lock(g_mutex);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    RDST_BY_WIDTH(elem_bytes, rc = (run_pipeline<K, LV>(static_cast<K*>(dev_keys), static_cast<K*>(dev_tmp), len, kind, 0, LV, true, true, s, nullptr, nullptr)));
+    RDST_BY_WIDTH(elem_bytes, rc = (sort_whole<K, LV>(static_cast<K*>(dev_keys), static_cast<K*>(dev_tmp), len, kind, s)));
     return rc;
 }
 

@@ -486,8 +486,9 @@ def set_hybrid(enabled=True, min_len=0):
     10 the default without the hybrid route as the atomic route's first fallback; 11 the default without the giant kernels
     (4-byte keys: a bucket of 65 536 keys and more sends the sort down the LSD route); 12 the default without the exact form
     of the MSD passes; 14 the default without the sample's prediction of the LSD route; 15 the default with the second form
-    of the 8-byte K4 (local_wide2_sort_kernel)."""
-    _lib.check(_lib.load().rdst_hip_set_hybrid(int(enabled) if enabled in (2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 14, 15) else int(bool(enabled)), int(min_len)))
+    of the 8-byte K4 (local_wide2_sort_kernel); 16 the default without the split of 8-byte slices beyond the atomic route's
+    window (run_split_sort); 17 the default with that split at every length, in eight parts (tests)."""
+    _lib.check(_lib.load().rdst_hip_set_hybrid(int(enabled) if enabled in (2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 14, 15, 16, 17) else int(bool(enabled)), int(min_len)))
 
 
 def release_workspace(device=None) -> None:

@@ -57,8 +57,9 @@ def test_workspace_size_is_reported(hiplib):
     assert big < 7_500_000_000
     # 8-byte keys: areas 9.1 GB, slots of whole keys 8.6 GB, status rows of eight levels ~2.1 GB
     assert hiplib.rdst_hip_workspace_bytes(1_000_000_000, 8) < 21_000_000_000
-    # below the routes' threshold (2^28 keys) only the LSD route's tables: a fraction of the slice
+    # below the routes' thresholds (3 * 2^26 u32 keys, 2^26 u64 keys) only the LSD route's tables: a fraction of the slice
     assert hiplib.rdst_hip_workspace_bytes(200_000_000, 4) < 200_000_000
+    assert hiplib.rdst_hip_workspace_bytes(60_000_000, 8) < 200_000_000 < hiplib.rdst_hip_workspace_bytes(70_000_000, 8)
     assert hiplib.rdst_hip_workspace_bytes(10, 3) == 0 and hiplib.rdst_hip_workspace_bytes(10, 16) > 0
 
 

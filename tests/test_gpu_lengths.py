@@ -66,7 +66,7 @@ def _check(torch, gpu, name, n, seed, shape):
     g = torch.Generator(device="cuda").manual_seed(seed)
     info = torch.iinfo(itype)
     src = torch.randint(info.min, info.max, (n,), dtype=itype, device="cuda", generator=g)
-    if shape == "half_top_bits":         # ids below half the range (from 2^28 keys up the sample lowers the window by a bit)
+    if shape == "half_top_bits":         # ids below half the range (from 2^26 keys up the sample lowers the window by a bit)
         src &= info.max
     elif shape == "one_heavy_byte":      # the first twentieth of the slice on one top byte: its areas overflow part-way
         sh = np.dtype(name).itemsize * 8 - 8
@@ -104,11 +104,16 @@ def test_lengths_around_the_grid_formulas(gpu, name, count, seed):
 
 
 def test_lengths_at_the_real_threshold(gpu):
-    """the shipped setting (routes considered from 2^28 keys up): the lengths right at the threshold"""
+    """the shipped setting (the atomic route is tried from 3 * 2^26 u32 keys and from 2^26 u64 keys up): the lengths right at
+    the thresholds, and at 2^28, from where the K1h hybrid route may follow a failed attempt"""
     import torch
-    for i, n in enumerate(((1 << 28) - 1, 1 << 28, (1 << 28) + 16_897, 300_000_017)):
+    t4, t8 = 3 << 26, 1 << 26
+    for i, n in enumerate((t4 - 1, t4, t4 + 16_897, (1 << 28) - 1, 1 << 28, 300_000_017)):
         r = _check(torch, gpu, "uint32", n, 0x5D570310 + i, "uniform")
-        assert r == ("lsd" if n < (1 << 28) else "atomic"), (n, r)
+        assert r == ("lsd" if n < t4 else "atomic"), (n, r)
+    for i, n in enumerate((t8 - 1, t8, t8 + 16_385, 100_000_003)):
+        r = _check(torch, gpu, "uint64", n, 0x5D570318 + i, "uniform")
+        assert r == ("lsd" if n < t8 else "atomic"), (n, r)
     gpu.device_status()
 
 
