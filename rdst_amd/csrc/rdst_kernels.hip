@@ -5279,18 +5279,23 @@ int run_pipeline(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, uint32_t level
     return workspace_release(*D, s);
 }
 
-// 8-byte keys beyond the atomic route's window (a uniform bucket of n / 65 536 keys no longer fits K4's tile: n > 1.04 x 10^9):
+// Keys beyond the atomic route's window (a uniform bucket of n / 65 536 keys no longer fits K4's tile: n > 1.04 x 10^9):
 // the reference recurses where a bucket is too big for the sort at hand (src/sorter.rs:131-138,
 // src/sorts/recombinating_sort.rs:68-88).  One exact scatter pass on the top byte (K1 counts that level, K3 moves the keys:
 // keys -> tmp, 24 bytes per key), its 256 counts come to the host, and aligned groups of top bytes — halved until the group
 // fits the window — are sorted as slices of their own: their keys share the group's top bits, so the sample lowers the window
 // past them and the atomic route takes the part as it takes a 10^9-key slice (48 bytes per key, result written straight into
-// the caller's array: deliver_tmp).  72 bytes per key where the LSD route moves 136.  A single top byte over the window is
+// the caller's array: deliver_tmp).  8-byte keys: 72 bytes per key where the LSD route moves 136; 4-byte keys: 32 against 36.  A single top byte over the window is
 // sorted by whatever run_pipeline picks for it (skewed keys: the LSD route).
+constexpr uint64_t SPLIT4_MIN_LEN = 1'300'000'000ull;
 bool split_eligible(uint64_t n, size_t key_bytes, int levels) {
-    if (key_bytes != 8 || levels != 8 || !g_tuning.split || !g_tuning.hybrid || !g_tuning.atomic_route || !g_tuning.atomic_wide || !g_tuning.count_sort || !g_tuning.wide2) return false;
+    if ((key_bytes != 4 && key_bytes != 8) || levels != (int)key_bytes || !g_tuning.split || !g_tuning.hybrid || !g_tuning.atomic_route || !g_tuning.count_sort) return false;
+    if (key_bytes == 8 && (!g_tuning.atomic_wide || !g_tuning.wide2)) return false;
     if (g_tuning.split_always) return n >= 2 && n < (1ull << 36);
-    return n >= atomic_min_len(8) && !atomic_eligible(n, 8, default_cfg(8, n, true)) && n < (1ull << 36);
+    if (n >= (1ull << 36) || n < atomic_min_len(key_bytes) || atomic_eligible(n, key_bytes, default_cfg(key_bytes, n, true))) return false;
+    // 4-byte keys have the K1h hybrid route beyond the window (24 bytes per key, every bucket the expanding K4's): 7.0 ms at 2^30
+    // keys where the split's 12 + 20 bytes per key take 8.1; from SPLIT4_MIN_LEN keys up the split wins (1.6 x 10^9: 14.1 -> 11 ms)
+    return key_bytes == 8 || n >= SPLIT4_MIN_LEN;
 }
 
 template <typename K, int LV>
@@ -5342,7 +5347,7 @@ int run_split_sort(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, hipStream_t 
 
 template <typename K, int LV>
 int sort_whole(K* keys, K* tmp, uint64_t n, rdst_key_kind kind, hipStream_t s) {
-    if constexpr (sizeof(K) == 8) {
+    if constexpr (sizeof(K) == 8 || sizeof(K) == 4) {
         if (split_eligible(n, sizeof(K), LV)) return run_split_sort<K, LV>(keys, tmp, n, kind, s);
     }
     return run_pipeline<K, LV>(keys, tmp, n, kind, 0, LV, true, true, s, nullptr, nullptr);
@@ -5777,8 +5782,8 @@ uint64_t rdst_hip_workspace_bytes(uint64_t len, uint32_t elem_bytes) {
     const uint64_t whole = make_layout(len, elem_bytes, elem_bytes, cfg, 0, halves, msd, giants).total;
     if (split_eligible(len, elem_bytes, (int)elem_bytes)) {  // the split pass's tables for the whole slice, then a part's areas and slots (a part is at most the window)
         uint64_t part = len < (1ull << 30) ? len : (1ull << 30) - 1;
-        while (part > (1ull << 26) && !atomic_eligible(part, 8, default_cfg(8, part, true))) part -= part / 64;
-        const uint64_t of_part = make_layout(part, 8, 8, default_cfg(8, part, true), 0, false, true, false).total;
+        while (part > (1ull << 26) && !atomic_eligible(part, elem_bytes, default_cfg(elem_bytes, part, true))) part -= part / 64;
+        const uint64_t of_part = make_layout(part, elem_bytes, elem_bytes, default_cfg(elem_bytes, part, true), 0, false, true, false).total;
         return whole > of_part ? whole : of_part;
     }
     return whole;

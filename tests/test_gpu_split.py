@@ -1,4 +1,4 @@
-"""8-byte keys beyond the atomic route's window (run_split_sort, rdst_kernels.hip): one exact scatter pass on the top byte, then
+"""4- and 8-byte keys beyond the atomic route's window (run_split_sort, rdst_kernels.hip): one exact scatter pass on the top byte, then
 aligned groups of top bytes as slices of their own, each delivered straight into the caller's array.  The reference recurses
 the same way where a bucket is too big for the sort at hand (src/sorter.rs:131-138, src/sorts/recombinating_sort.rs:68-88).
 Mode 17 forces the split at every length (eight groups of 32 top bytes), so the parts, their offsets and every route a part can
@@ -11,7 +11,7 @@ from helpers import mapped_key, random_bits, reference_sorted, same_bits, to_dev
 
 pytestmark = pytest.mark.gpu
 
-WIDE = ("uint64", "int64", "float64")
+WIDE = ("uint32", "int32", "float32", "uint64", "int64", "float64")
 
 
 @pytest.fixture
@@ -37,9 +37,11 @@ def test_split_with_empty_heavy_and_single_key_groups(split, dtype):
     next route inside the part; the result must still land in the caller's array)"""
     n = 3_000_000
     a = random_bits(n, dtype, 0x5D570410).copy()
-    u = a.view(np.uint64)
-    u[: n - n // 50] = (u[: n - n // 50] & np.uint64(0x00FFFFFFFFFFFFFF)) | np.uint64(0x47 << 56)   # 98 % on one top byte
-    u[n - 5] = np.uint64(0x01 << 56) | np.uint64(5)                                                   # a group with one key
+    ut = np.dtype(f"u{a.dtype.itemsize}").type
+    sh = 8 * a.dtype.itemsize - 8
+    u = a.view(ut)
+    u[: n - n // 50] = (u[: n - n // 50] & ut((1 << sh) - 1)) | ut(0x47 << sh)   # 98 % on one top byte
+    u[n - 5] = ut(0x01 << sh) | ut(5)                                             # a group with one key
     for order in ("random", "sorted", "reversed"):
         b = a if order == "random" else reference_sorted(a) if order == "sorted" else reference_sorted(a)[::-1].copy()
         d = to_device(b)
@@ -92,4 +94,21 @@ def test_two_pow_30_u64_keys_take_the_split_by_default(gpu):
         assert bool(torch.equal(lsd, keys))
     finally:
         gpu.set_hybrid(True, 0)
+    gpu.device_status()
+
+
+def test_u32_keys_beyond_the_window_take_the_split_by_default(gpu):
+    """1.4 x 10^9 uniform u32 keys: past 1.3 x 10^9 the split (12 + 20 bytes per key) beats the K1h hybrid route (24 and every
+    bucket the expanding K4's)"""
+    import torch
+    n = 1_400_000_000
+    g = torch.Generator(device="cuda").manual_seed(0x5D570440)
+    src = torch.randint(-(2**31), 2**31, (n,), dtype=torch.int32, device="cuda", generator=g)
+    keys = src.clone()
+    gpu.sort_device_tensor(keys.view(torch.uint32))
+    assert gpu.last_route() == "atomic"
+    k = keys ^ torch.iinfo(torch.int32).min
+    assert bool((k[1:] >= k[:-1]).all())
+    del k
+    assert int(keys.sum()) == int(src.sum()) and int((keys ^ (keys >> 9)).sum()) == int((src ^ (src >> 9)).sum())
     gpu.device_status()
