@@ -28,7 +28,7 @@ def hybrid(gpu, request):
     8-byte keys try the atomic route (MSD passes that claim space, no counting read), then the hybrid one, then LSD
     ("atomic_4_only": 8-byte keys start at the hybrid route; "atomic_then_lsd": no hybrid route behind a failed atomic one;
     "no_giants": without the giant kernels — a 4-byte bucket of 65 536 keys and more sends the sort down the LSD route)."""
-    gpu.set_hybrid(MODES[request.param], min_len=1)   # consider the routes at every length (default: 2^28 and up)
+    gpu.set_hybrid(MODES[request.param], min_len=1)   # consider the routes at every length (default: from 2^26 u64 / 3 * 2^26 u32 keys up)
     gpu._test_mode = request.param
     yield gpu
     gpu.set_hybrid(True, 0)
@@ -261,7 +261,9 @@ def test_two_thousand_giants(hybrid):
     top = np.bincount((a >> np.uint32(16)).astype(np.int64), minlength=65536)
     assert (top >= 65536).sum() == 2048
     got, route = _sort(hybrid, a)
-    assert route == ("hybrid" if _giants_ok(hybrid, "uint32") else "lsd")
+    # (137 M keys: from 2^26 keys up there is a sample, it sees the five shared top bits and lowers the window past them — the
+    # modes that try the atomic route first need no giants; "count" starts at the K1h hybrid route and has its 2 048)
+    assert route == ("atomic" if _takes_atomic(hybrid, "uint32") else "hybrid" if _giants_ok(hybrid, "uint32") else "lsd")
     assert same_bits(got, reference_sorted(a))
 
 
