@@ -64,7 +64,7 @@ while time.time() - t0 < budget:
     if os.environ.get("RDST_STRESS_TYPES") and name not in os.environ["RDST_STRESS_TYPES"].split(","): continue
     kind = int(torch.randint(0, 14, (1,)))
     # route knobs: the default, the routes considered at every length, and the A/B modes
-    mode = [1, 1, 1, 7, 8, 10, 11, 3, 9, 14, 15, 12][int(torch.randint(0, 12, (1,)))]
+    mode = [1, 1, 1, 7, 8, 10, 11, 3, 9, 14, 15, 12, 16, 17, 17][int(torch.randint(0, 15, (1,)))]
     rdst_amd.set_hybrid(mode, 1 if int(torch.randint(0, 3, (1,))) else 0)
     total_keys += n; big += n > 1_000_000
     split, fast = bool(torch.randint(0, 2, (1,))), int(torch.randint(0, 3, (1,)))
