@@ -7,7 +7,7 @@ import rdst_amd
 
 name = sys.argv[1] if len(sys.argv) > 1 else "uint32"
 modes = [int(x) for x in sys.argv[2:]] or [1, 3, 2, 0]
-n = 1_000_000_000
+n = int(float(os.environ.get("RDST_N", "1e9")))
 cfg = int(os.environ.get("RDST_CFG", "-1"))
 if cfg >= 0:
     rdst_amd.set_tuning(pass_config=cfg)
