@@ -137,7 +137,10 @@ int rdst_hip_host_timing(float* h2d_ms, float* sort_ms, float* d2h_ms);
  * (the `tmp_bucket` of src/sorts/lsb_sort.rs:53).  Asynchronous on `stream`.  The LSD
  * pass loop is the device twin of Sorter::lsb_sort_adapter (src/sorts/lsb_sort.rs:39-127)
  * with mt_lsb_sort's (bucket, tile) offset table (src/sorts/mt_lsb_sort.rs:40-133)
- * replaced by an on-device chained scan. */
+ * replaced by an on-device chained scan.  One exception to "asynchronous": 4- and 8-byte keys beyond the byte-saving routes'
+ * window (more than ~1.04e9 8-byte keys, 1.3e9 4-byte keys) are split on their top byte and sorted part by part, as
+ * Sorter recurses into a bucket too big for the sort at hand (src/sorter.rs:131-138); the 256 counts of that split come to
+ * the host, so the call waits once for `stream` and enqueues the rest. */
 int rdst_hip_sort_device(void* dev_keys, void* dev_tmp, uint64_t len, uint32_t elem_bytes,
                          rdst_key_kind kind, uint32_t levels, void* stream);
 
@@ -321,7 +324,9 @@ int rdst_hip_profile_run_stages(int run, uint32_t* stages_out, uint32_t capacity
  * every width with one detail changed, for A/B runs and tests — 2: ranked in-LDS sort for 4-byte keys as well, 3: pass L-1
  * hands K4 whole keys instead of 16-bit halves, 5: no key sample, 6: 8-byte keys with the one-block-per-CU form of K4, 9: no
  * expanding K4 (4-byte buckets up to one tile only); 8: the atomic route for 4-byte keys only; 10: a failed atomic route
- * falls straight to LSD; 11: no giant kernels.  min_len == 0 keeps the built-in thresholds (atomic route: 3 * 2^26 4-byte keys, 2^26 8-byte keys; K1h hybrid route: 2^28).  Results are identical
+ * falls straight to LSD; 11: no giant kernels; 12: no exact form of the MSD passes; 14: no prediction of the LSD route
+ * from the sample; 15: the second form of the 8-byte K4; 16: no split of slices beyond the window; 17: that split at every
+ * length, in eight parts.  min_len == 0 keeps the built-in thresholds (atomic route: 3 * 2^26 4-byte keys, 2^26 8-byte keys; K1h hybrid route: 2^28).  Results are identical
  * on every route.  Not part of the reference surface. */
 int rdst_hip_set_hybrid(int enabled, uint64_t min_len);
 

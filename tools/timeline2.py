@@ -1,6 +1,6 @@
-"""Development aid: where a workgroup's life goes in local_wide2_sort_kernel (which = 1) or msd_scatter_kernel pass A / B
-(2 / 3): thread 0's shader-clock stamps, from a -DRDST_EXPERIMENTS build (tools/_build/librdst_hip_exp.so).
-    python tools/timeline2.py <uint32|uint64> <which> [n]"""
+"""Development aid: where a workgroup's life goes in the 8-byte K4 (which = 1), msd_scatter_kernel pass A / B (2 / 3) or the
+expanding 4-byte K4 (5): thread 0's shader-clock stamps, from a -DRDST_EXPERIMENTS build (tools/_build/librdst_hip_exp.so).
+    python tools/timeline2.py <uint32|uint64|float32n|uint32g> <which> [n]"""
 import ctypes, os, sys
 import numpy as np
 import torch
@@ -24,7 +24,6 @@ elif name == "uint32g":  # a bell over the whole range (sum of four uniforms): t
 else:
     it = torch.int32 if name == "uint32" else torch.int64
     info = torch.iinfo(it)
-if "src" not in dir():
     src = torch.randint(info.min, info.max, (n,), dtype=it, device="cuda", generator=g)
 keys, tmp = src.clone(), torch.empty_like(src)
 view, tview = keys.view(getattr(torch, name)), tmp.view(getattr(torch, name))
