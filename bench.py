@@ -232,10 +232,10 @@ def exact_against_torch_sort(torch, src, out, name):
 
 
 def mix_checksum(torch, x, chunk=1 << 27):
-    """(sum, sum of a bit-mixed image) of an int64 tensor, both mod 2^64, in bounded temporaries"""
+    """(sum, sum of a bit-mixed image) of an integer tensor, both mod 2^64, in bounded temporaries"""
     a = b = 0
     for s in range(0, x.numel(), chunk):
-        c = x[s:s + chunk]
+        c = x[s:s + chunk].to(torch.int64)
         a = (a + int(c.sum())) & (2**64 - 1)
         m = (c * -7046029254386353131) ^ (c >> 29)
         b = (b + int(m.sum())) & (2**64 - 1)
@@ -276,6 +276,40 @@ def big_u64_config(torch, rdst_amd, n_big):
     del src, buf, tmp, out
     torch.cuda.empty_cache()
     return res
+
+
+def size_points(torch, rdst_amd):
+    """The rate outside the 10^9-key sweet spot (the whole sweep: profiles/r03_size_sweep.json): short slices,
+    where K4's 65 536 workgroups are a floor, and slices beyond the byte-saving routes' window, which are split on their top
+    byte.  Best of 3 after a warm-up, sortedness and a checksum checked outside the clock."""
+    out = {}
+    for name, n in (("u32", 100_000_000), ("u32", 250_000_000), ("u32", 2_000_000_000), ("u64", 100_000_000), ("u64", 1 << 31)):
+        free, _total = torch.cuda.mem_get_info()
+        kb = DTYPES[name][2]
+        if free < 3 * kb * n + 30 * 2**30:
+            out[f"{name}_{n}"] = {"skipped": "not enough free HBM"}
+            continue
+        src = gen_keys(torch, n, name, 0x5D570020 + len(out))
+        buf = torch.empty_like(src).view(getattr(torch, DTYPES[name][0]))
+        tmp = torch.empty_like(buf)
+        ms = []
+        for _ in range(4):
+            buf.view(src.dtype).copy_(src)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rdst_amd.sort_device_tensor(buf, tmp, check=False)
+            e1.record()
+            torch.cuda.synchronize()
+            ms.append(e0.elapsed_time(e1))
+        rdst_amd.device_status()
+        res = buf.view(src.dtype)
+        assert is_sorted(torch, mapped_signed(torch, res, name)) and mix_checksum(torch, res) == mix_checksum(torch, src), f"size point {name} {n}"
+        best = min(ms[1:])
+        out[f"{name}_{n}"] = {"keys": n, "route": rdst_amd.last_route(), "ms_per_step": round(best, 3), "Gkeys_per_s": round(n / best / 1e6, 2)}
+        del src, buf, tmp, res
+        torch.cuda.empty_cache()
+        rdst_amd.release_workspace()
+    return out
 
 
 ROUTE_TEXT = {
@@ -557,6 +591,7 @@ def main():
         del src
         torch.cuda.empty_cache()
         if not args.no_extras and not args.no_big and n == KEYS_PER_GPU:
+            line.setdefault("configs", {})["other_sizes"] = size_points(torch, rdst_amd)
             line.setdefault("configs", {})["u64_8e9"] = big_u64_config(torch, rdst_amd, 8 * KEYS_PER_GPU)
         line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(host_keys, gpu_sorted_host)
     elif rank == 0:
