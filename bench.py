@@ -414,10 +414,35 @@ def main():
     kernels = kernel_table(rdst_amd, runs, n if not distributed else out.numel(), kb, levels)
     rdst_amd.set_profiling(False)
 
+    breakdown = None
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # outside the clock: where a sharded step's time goes (two more steps with events between the stages; max over ranks), and
+        # what one rank's shard costs on its own GPU without the exchange (the same dtype: the N = 1 line of this bench is u32)
+        stages = ("split", "counts_and_plan", "exchange", "local_sort")
+        tm = {}
+        for _ in range(2):
+            tm = {}
+            bufs[0].view(src.dtype).copy_(src)
+            sharded_sort(bufs[0], timings=tm)
+        alone = []
+        for _ in range(3):
+            bufs[0].view(src.dtype).copy_(src)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rdst_amd.sort_device_tensor(bufs[0], tmp, check=False)
+            e1.record()
+            torch.cuda.synchronize()
+            alone.append(e0.elapsed_time(e1))
+        t = torch.tensor([tm.get(k, 0.0) for k in stages] + [min(alone)], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        vals = [round(float(x), 3) for x in t.tolist()]
+        breakdown = {"stages_ms_max_over_ranks": dict(zip(stages, vals[:4])), "one_shard_sorted_alone_ms": vals[4],
+                     "one_shard_sorted_alone_Gkeys_per_s": round(n / vals[4] / 1e6, 2),
+                     "what": "events between the stages of one more sharded step (outside the clock); the last two figures: this "
+                             "dtype's single-GPU sort of one rank's shard, no exchange"}
 
     # sanity of the last result (outside the clock): sorted, and (single GPU) the same multiset as its input
     itype = torch.int32 if kb == 4 else torch.int64
@@ -471,6 +496,8 @@ def main():
             "roofline": roof,
             "kernels": kernels,
         }
+        if breakdown:
+            line["sharded_breakdown"] = breakdown
 
     if rank == 0 and not distributed:
         # ---- outside the timed region: copy ceiling, the other BASELINE configs, end to end, CPU leg

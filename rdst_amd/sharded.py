@@ -118,12 +118,28 @@ def _splits(table, owner, rank, world):
     return torch.cat([send, recv, share.max()[None], table.sum()[None]])
 
 
-def sharded_sort(local_keys, group=None, engine=None, return_info: bool = False, force_collectives: bool = False):
+def sharded_sort(local_keys, group=None, engine=None, return_info: bool = False, force_collectives: bool = False, timings=None):
     """Globally sort the concatenation of every rank's `local_keys`; returns this rank's slice
     (a new tensor whose length is the number of keys that fall into this rank's range).
-    Collective: every rank of `group` must call it."""
+    Collective: every rank of `group` must call it.  `timings` (a dict, device tensors only): filled with the milliseconds this
+    rank spent per stage — split, counts + plan, exchange, local sort — from events on the current stream; the call then ends
+    with a synchronisation (a diagnostic step, not the timed path)."""
     import torch
     import torch.distributed as dist
+
+    marks = []
+
+    def mark(stage):
+        if timings is not None and local_keys.is_cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            marks.append((stage, ev))
+
+    def close_marks():
+        if marks:
+            torch.cuda.synchronize()
+            for (_, a), (stage, b) in zip(marks[:-1], marks[1:]):
+                timings[stage] = timings.get(stage, 0.0) + a.elapsed_time(b)
 
     if engine is None:
         engine = HipEngine()
@@ -145,7 +161,9 @@ def sharded_sort(local_keys, group=None, engine=None, return_info: bool = False,
         return torch.stack(gathered).to(counts.device)                 # [rank][bucket], where the counts live
 
     # 1. + 2.  top-digit split of my shard, counts stay on the device; all-gather of the 256 counts
+    mark("start")
     grouped, counts = engine.split_top_level(local_keys)
+    mark("split")
     table = gather_table(counts)
     # 3.  digit -> owner, split sizes: device arithmetic, one small copy to the host
     owner = _owners(table, world)
@@ -162,6 +180,7 @@ def sharded_sort(local_keys, group=None, engine=None, return_info: bool = False,
         split_bits = 16
     send = [int(x) for x in plan[:world]]
     recv = [int(x) for x in plan[world:2 * world]]
+    mark("counts_and_plan")
     # 4.  exchange
     inbox = engine.empty(sum(recv), local_keys)
     as_int = {1: torch.int8, 2: torch.int16, 4: torch.int32, 8: torch.int64}[local_keys.element_size()]
@@ -174,8 +193,11 @@ def sharded_sort(local_keys, group=None, engine=None, return_info: bool = False,
         dist.all_to_all_single(inbox.view(as_int), grouped.view(as_int), output_split_sizes=recv,
                                input_split_sizes=send, group=group)
     del grouped
+    mark("exchange")
     # 5.  local sort over every level (arrivals are only range-partitioned)
     engine.sort(inbox)
+    mark("local_sort")
+    close_marks()
     if return_info:
         return inbox, {"owner": owner.cpu().tolist(), "recv": recv, "send": send, "split_bits": split_bits}
     return inbox
