@@ -318,11 +318,12 @@ ROUTE_TEXT = {
 }
 
 
-def timed_sorts(torch, rdst_amd, src, name, K, W, step=None, fence=None):
+def timed_sorts(torch, rdst_amd, src, name, K, W, step=None, fence=None, in_place=True):
     """W warm-up + K timed sorts of fresh copies of `src` (already in HBM).  Returns (elapsed s, per-step ms,
-    profiled run indices, last output)."""
+    profiled run indices, last output).  in_place=False: `step` leaves its input alone (the sharded sort returns a new
+    tensor), so every step reads `src` itself — 25 copies of a 10^9-key u64 shard would be 200 GB per GPU."""
     view_dt = getattr(torch, DTYPES[name][0])
-    bufs = [src.clone().view(view_dt) for _ in range(K + W)]
+    bufs = [src.clone().view(view_dt) for _ in range(K + W)] if in_place else [src.view(view_dt)] * (K + W)
     tmp = torch.empty_like(bufs[0])
     if step is None:
         def step(buf):  # noqa: E306
@@ -409,7 +410,7 @@ def main():
 
     src = gen_keys(torch, n, name, seed + rank)
     step = (lambda buf: sharded_sort(buf)) if distributed else None
-    elapsed, per_step, runs, out, bufs, tmp = timed_sorts(torch, rdst_amd, src, name, K, W, step=step, fence=fence)
+    elapsed, per_step, runs, out, bufs, tmp = timed_sorts(torch, rdst_amd, src, name, K, W, step=step, fence=fence, in_place=not distributed)
     route = rdst_amd.last_route()
     kernels = kernel_table(rdst_amd, runs, n if not distributed else out.numel(), kb, levels)
     rdst_amd.set_profiling(False)
@@ -425,14 +426,14 @@ def main():
         tm = {}
         for _ in range(2):
             tm = {}
-            bufs[0].view(src.dtype).copy_(src)
-            sharded_sort(bufs[0], timings=tm)
+            sharded_sort(bufs[0], timings=tm)   # (leaves its input alone)
         alone = []
+        work = torch.empty_like(bufs[0])
         for _ in range(3):
-            bufs[0].view(src.dtype).copy_(src)
+            work.view(src.dtype).copy_(src)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            rdst_amd.sort_device_tensor(bufs[0], tmp, check=False)
+            rdst_amd.sort_device_tensor(work, tmp, check=False)
             e1.record()
             torch.cuda.synchronize()
             alone.append(e0.elapsed_time(e1))
