@@ -3324,15 +3324,26 @@ __global__ __launch_bounds__(GIANT_THREADS) void giant_count_kernel(
                 for (int j = 0; j < U2; ++j) {
                     const uint64_t p = base + ((uint64_t)j * BLOCK + (uint64_t)tid) * 8;
                     const uint32_t w[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const uint32_t x = (w[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu;
-                        const bool mine = p + e >= g0 && p + e < g1 && (x >> 15) == half;
+                    // (all but a chunk's first and last wave: every lane's eight halves are the chunk's — no 64-bit bounds per key)
+                    auto add = [&](uint32_t x, bool mine) {
                         const uint32_t x0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
                         if (__all((int)(mine && x == x0)) != 0) {
                             if (lane == 0) atomicAdd(&tab[x0 & 0x7FFFu], 64u);
                         } else if (mine) {
                             atomicAdd(&tab[x & 0x7FFFu], 1u);
+                        }
+                    };
+                    if (__all((int)(p >= g0 && p + 8 <= g1)) != 0) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const uint32_t x = (w[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu;
+                            add(x, (x >> 15) == half);
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const uint32_t x = (w[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu;
+                            add(x, p + e >= g0 && p + e < g1 && (x >> 15) == half);
                         }
                     }
                 }
