@@ -2929,9 +2929,18 @@ __global__ __launch_bounds__(EXPAND_THREADS) void local_expand_sort_kernel(
                     const uint64_t p = base + ((uint64_t)j * BLOCK + (uint64_t)tid) * 8;
                     const uint32_t w[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
                     const bool whole = p >= g0 && p + 8 <= g1;  // all eight halves are the bucket's
-                    const uint32_t x0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(w[0] & 0xFFFFu)), pair0 = x0 | (x0 << 16);
-                    if (__all((int)(whole && w[0] == pair0 && w[1] == pair0 && w[2] == pair0 && w[3] == pair0)) != 0) {
-                        if (lane == 0) atomicAdd(&tab[word_of(x0)], 512u << ((x0 & 1u) * 16u));  // 512 keys of one value: one add, not 512 on one address
+                    // the lanes hold the SAME eight halves (a constant, a pattern whose period divides eight): 64 keys per value and add
+                    // would be 64 adds on one address — one lane adds 64 per half instead
+                    const uint32_t f[4] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)w[0]), (uint32_t)__builtin_amdgcn_readfirstlane((int)w[1]),
+                                           (uint32_t)__builtin_amdgcn_readfirstlane((int)w[2]), (uint32_t)__builtin_amdgcn_readfirstlane((int)w[3])};
+                    if (__all((int)(whole && w[0] == f[0] && w[1] == f[1] && w[2] == f[2] && w[3] == f[3])) != 0) {
+                        if (lane == 0) {
+#pragma unroll
+                            for (int h = 0; h < 8; ++h) {
+                                const uint32_t x = (f[h >> 1] >> ((h & 1) * 16)) & 0xFFFFu;
+                                atomicAdd(&tab[word_of(x)], 64u << ((x & 1u) * 16u));
+                            }
+                        }
                     } else if (whole) {
 #pragma unroll
                         for (int h = 0; h < 8; ++h) {
@@ -3334,10 +3343,24 @@ __global__ __launch_bounds__(GIANT_THREADS) void giant_count_kernel(
                         }
                     };
                     if (__all((int)(p >= g0 && p + 8 <= g1)) != 0) {
+                        // 64 keys of one value in a wave's add are 64 adds on one address: that happens when the lanes hold the SAME
+                        // eight halves (a constant, or a pattern whose period divides eight) — tested once per vector, not per key
+                        const uint32_t f[4] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)w[0]), (uint32_t)__builtin_amdgcn_readfirstlane((int)w[1]),
+                                               (uint32_t)__builtin_amdgcn_readfirstlane((int)w[2]), (uint32_t)__builtin_amdgcn_readfirstlane((int)w[3])};
+                        if (__all((int)(w[0] == f[0] && w[1] == f[1] && w[2] == f[2] && w[3] == f[3])) != 0) {
+                            if (lane == 0) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const uint32_t x = (w[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu;
-                            add(x, (x >> 15) == half);
+                                for (int e = 0; e < 8; ++e) {
+                                    const uint32_t x = (f[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu;
+                                    if ((x >> 15) == half) atomicAdd(&tab[x & 0x7FFFu], 64u);
+                                }
+                            }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const uint32_t x = (w[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu;
+                                if ((x >> 15) == half) atomicAdd(&tab[x & 0x7FFFu], 1u);
+                            }
                         }
                     } else {
 #pragma unroll
