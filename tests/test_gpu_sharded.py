@@ -119,10 +119,13 @@ def _nccl_worker(rank, world, port, out_dir):
         from rdst_amd.sharded import sharded_sort
         for dtype_name in ("uint64", "uint32", "float32", "int64"):
             a = random_bits(2_000_003, dtype_name, seed=0x5D570040).copy()
-            out, info = sharded_sort(to_device(a), return_info=True, force_collectives=True)
+            tm = {}
+            out, info = sharded_sort(to_device(a), return_info=True, force_collectives=True, timings=tm)
             rdst_amd.device_status()
             assert info["recv"] == [a.size] and info["send"] == [a.size], info
             assert same_bits(to_host(out, dtype_name), reference_sorted(a)), dtype_name
+            # the stage clock bench.py's N > 1 line reports (`sharded_breakdown`): every stage seen, none negative
+            assert set(tm) == {"split", "counts_and_plan", "exchange", "local_sort"} and min(tm.values()) >= 0.0, tm
         open(os.path.join(out_dir, "ok"), "w").write("ok")
     finally:
         dist.destroy_process_group()
